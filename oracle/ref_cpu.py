@@ -1,0 +1,301 @@
+"""CPU oracle for the I_ea predict hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module.  The shipped path (``speech_inpainting_amd``) never calls into it and fails loudly when the HIP
+library is missing.
+
+It is a plain-torch (fp32, CPU) restatement of the reference's arithmetic, one function per row of
+SURVEY.md section 8(a).  It imports neither ``transformers`` nor anything from the reference, so it can
+travel to the GPU box.  Citations are ``/root/reference/...`` paths unless they start with
+``transformers/`` (the third-party package that holds the HuBERT arithmetic; the reference pins
+transformers==4.35.0, requirements.txt:8, and calls it at I_ea/model.py:1,32,39-40,82-85).
+
+Pinning: the reference holds no tests or golden vectors for this path, so the oracle
+is pinned against outputs of the reference's own modules run in the authoring container
+(tools/make_goldens.py -> tests/golden/*.npz; checked by tests/test_oracle_golden.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+LRELU_SLOPE = 0.1  # I_ea/hifi_gan/models.py:9
+
+
+# ----------------------------------------------------------------------------- A0
+def mask_and_normalize(wave: torch.Tensor, mask_start: Sequence[int], mask_len: Sequence[int]) -> torch.Tensor:
+    """A0.  Zero samples [start, start+len) of each clip (I_ea/predict.py:132-133), then the HF processor's
+    zero-mean/unit-variance normalisation ``(x - mean) / sqrt(var + 1e-7)`` with the population variance
+    (transformers/models/wav2vec2/feature_extraction_wav2vec2.py:60,66).  wave: (B, N) fp32."""
+    x = wave.clone().float()
+    for b in range(x.shape[0]):
+        s, l = int(mask_start[b]), int(mask_len[b])
+        if l > 0:
+            x[b, s:s + l] = 0.0
+    mean = x.mean(dim=1, keepdim=True)
+    var = x.var(dim=1, unbiased=False, keepdim=True)
+    return (x - mean) / torch.sqrt(var + 1e-7)
+
+
+def mask_samples_from_frames(frame_pos: int, frame_len: int) -> Tuple[int, int]:
+    """Sample span the reference zeroes for a frame-level mask:
+    ``[pos*320+80, (pos+len)*320+79-80)`` (I_ea/predict.py:133).  Returns (start, length)."""
+    s = frame_pos * 320 + 80
+    e = (frame_pos + frame_len) * 320 + 79 - 80
+    return s, max(e - s, 0)
+
+
+# ----------------------------------------------------------------------------- weight helpers
+def fold_weight_norm(g: torch.Tensor, v: torch.Tensor, dim: int) -> torch.Tensor:
+    """w = g * v / ||v||, norm over every dim except `dim` (torch.nn.utils.weight_norm)."""
+    dims = [d for d in range(v.dim()) if d != dim]
+    return v * (g / v.pow(2).sum(dim=dims, keepdim=True).sqrt())
+
+
+def _get(sd: Dict[str, torch.Tensor], *names: str) -> torch.Tensor:
+    for n in names:
+        if n in sd:
+            return sd[n].float()
+    raise KeyError(names[0])
+
+
+def _conv_weight(sd, prefix: str, dim: int = 0) -> torch.Tensor:
+    """Folded or un-folded conv weight (I_ea/hifi_gan/models.py:125-132 remove_weight_norm)."""
+    if prefix + ".weight" in sd:
+        return sd[prefix + ".weight"].float()
+    if prefix + ".weight_g" in sd:
+        return fold_weight_norm(sd[prefix + ".weight_g"].float(), sd[prefix + ".weight_v"].float(), dim)
+    g = sd[prefix + ".parametrizations.weight.original0"].float()
+    v = sd[prefix + ".parametrizations.weight.original1"].float()
+    return fold_weight_norm(g, v, dim)
+
+
+# ----------------------------------------------------------------------------- A1..A9 HuBERT
+def hubert_feature_extractor(sd, arch, x: torch.Tensor, prefix: str = "base_model.") -> torch.Tensor:
+    """A1/A1'/A2.  (B, N) normalised wave -> (B, C, T).
+    group: conv0 -> GroupNorm(C groups) -> GELU, then conv -> GELU (transformers/models/hubert/modeling_hubert.py:154-175,106-124)
+    layer: every layer conv(+bias) -> LayerNorm over channels -> GELU (:127-151)."""
+    h = x[:, None, :]
+    for i, (k, s) in enumerate(zip(arch.conv_kernel, arch.conv_stride)):
+        p = f"{prefix}feature_extractor.conv_layers.{i}."
+        w = sd[p + "conv.weight"].float()
+        b = sd[p + "conv.bias"].float() if arch.conv_bias else None
+        h = F.conv1d(h, w, b, stride=s)
+        if arch.feat_extract_norm == "group" and i == 0:
+            h = F.group_norm(h, w.shape[0], sd[p + "layer_norm.weight"].float(), sd[p + "layer_norm.bias"].float(), 1e-5)
+        elif arch.feat_extract_norm == "layer":
+            h = F.layer_norm(h.transpose(1, 2), (w.shape[0],), sd[p + "layer_norm.weight"].float(),
+                             sd[p + "layer_norm.bias"].float(), 1e-5).transpose(1, 2)
+        h = F.gelu(h)
+    return h
+
+
+def hubert_attention(sd, arch, p: str, h: torch.Tensor) -> torch.Tensor:
+    """A6.  Eager attention: softmax(q k^T * d^-0.5) v, then out_proj (modeling_hubert.py:234-259,262-344)."""
+    B, T, H = h.shape
+    nh, hd = arch.num_attention_heads, arch.head_dim
+    q = F.linear(h, sd[p + "q_proj.weight"].float(), sd[p + "q_proj.bias"].float()).view(B, T, nh, hd).transpose(1, 2)
+    k = F.linear(h, sd[p + "k_proj.weight"].float(), sd[p + "k_proj.bias"].float()).view(B, T, nh, hd).transpose(1, 2)
+    v = F.linear(h, sd[p + "v_proj.weight"].float(), sd[p + "v_proj.bias"].float()).view(B, T, nh, hd).transpose(1, 2)
+    w = torch.matmul(q, k.transpose(2, 3)) * (hd ** -0.5)
+    w = F.softmax(w, dim=-1)
+    o = torch.matmul(w, v).transpose(1, 2).reshape(B, T, H)
+    return F.linear(o, sd[p + "out_proj.weight"].float(), sd[p + "out_proj.bias"].float())
+
+
+def hubert_ffn(sd, p: str, h: torch.Tensor) -> torch.Tensor:
+    """A7.  Linear -> GELU(erf) -> Linear (modeling_hubert.py:347-368)."""
+    h = F.gelu(F.linear(h, sd[p + "intermediate_dense.weight"].float(), sd[p + "intermediate_dense.bias"].float()))
+    return F.linear(h, sd[p + "output_dense.weight"].float(), sd[p + "output_dense.bias"].float())
+
+
+def hubert_pos_conv(sd, arch, prefix: str, h: torch.Tensor) -> torch.Tensor:
+    """A4.  Weight-normed (dim=2) grouped Conv1d(k, pad=k//2), drop the last frame for even k, GELU
+    (modeling_hubert.py:45-92,95-103)."""
+    p = prefix + "encoder.pos_conv_embed.conv"
+    w = _conv_weight(sd, p, dim=2)
+    k = arch.num_conv_pos_embeddings
+    y = F.conv1d(h.transpose(1, 2), w, sd[p + ".bias"].float(), padding=k // 2,
+                 groups=arch.num_conv_pos_embedding_groups)
+    if k % 2 == 0:
+        y = y[:, :, :-1]
+    return F.gelu(y).transpose(1, 2)
+
+
+def hubert_encode(sd, arch, x_norm: torch.Tensor, prefix: str = "base_model.", taps: Optional[dict] = None) -> torch.Tensor:
+    """A1..A8.  HubertModel.forward in eval mode with an all-ones attention mask
+    (modeling_hubert.py:878-947; encoder :407-476 post-LN, :550-623 pre-LN 'stable')."""
+    eps = arch.layer_norm_eps
+    f = hubert_feature_extractor(sd, arch, x_norm, prefix).transpose(1, 2)          # (B, T, C)
+    if taps is not None:
+        taps["features"] = f
+    p = prefix + "feature_projection."
+    if arch.feat_proj_layer_norm:
+        f = F.layer_norm(f, (f.shape[-1],), sd[p + "layer_norm.weight"].float(), sd[p + "layer_norm.bias"].float(), eps)
+    h = F.linear(f, sd[p + "projection.weight"].float(), sd[p + "projection.bias"].float())
+    if taps is not None:
+        taps["projected"] = h
+    h = h + hubert_pos_conv(sd, arch, prefix, h)
+    e = prefix + "encoder."
+    H = arch.hidden_size
+    if not arch.do_stable_layer_norm:
+        h = F.layer_norm(h, (H,), sd[e + "layer_norm.weight"].float(), sd[e + "layer_norm.bias"].float(), eps)
+    if taps is not None:
+        taps["encoder_in"] = h
+    for l in range(arch.num_hidden_layers):
+        L = f"{e}layers.{l}."
+        if arch.do_stable_layer_norm:
+            a = F.layer_norm(h, (H,), sd[L + "layer_norm.weight"].float(), sd[L + "layer_norm.bias"].float(), eps)
+            h = h + hubert_attention(sd, arch, L + "attention.", a)
+            f2 = F.layer_norm(h, (H,), sd[L + "final_layer_norm.weight"].float(), sd[L + "final_layer_norm.bias"].float(), eps)
+            h = h + hubert_ffn(sd, L + "feed_forward.", f2)
+        else:
+            h = h + hubert_attention(sd, arch, L + "attention.", h)
+            h = F.layer_norm(h, (H,), sd[L + "layer_norm.weight"].float(), sd[L + "layer_norm.bias"].float(), eps)
+            h = h + hubert_ffn(sd, L + "feed_forward.", h)
+            h = F.layer_norm(h, (H,), sd[L + "final_layer_norm.weight"].float(), sd[L + "final_layer_norm.bias"].float(), eps)
+        if taps is not None and l == 0:
+            taps["layer0"] = h
+    if arch.do_stable_layer_norm:
+        h = F.layer_norm(h, (H,), sd[e + "layer_norm.weight"].float(), sd[e + "layer_norm.bias"].float(), eps)
+    return h
+
+
+def custom_model_forward(sd, arch, x_norm: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+    """A9.  CustomModel.forward: final_layers = LayerNorm(H) -> Linear(H, codebook_dim) on last_hidden_state
+    (I_ea/model.py:75-78,80-89).  Returns (B, T, codebook_dim)."""
+    h = hubert_encode(sd, arch, x_norm, "base_model.", taps)
+    if taps is not None:
+        taps["last_hidden"] = h
+    h = F.layer_norm(h, (arch.hidden_size,), sd["final_layers.0.weight"].float(), sd["final_layers.0.bias"].float(), 1e-5)
+    return F.linear(h, sd["final_layers.1.weight"].float(), sd["final_layers.1.bias"].float())
+
+
+# ----------------------------------------------------------------------------- A10..A13 codebook
+def gather_masked_frames(outputs: torch.Tensor, frame_pos: Sequence[int], lm: int) -> torch.Tensor:
+    """A10.  values[i] = outputs[i, pos_i : pos_i + Lm] (I_ea/predict.py:164-168)."""
+    return torch.stack([outputs[i, int(frame_pos[i]):int(frame_pos[i]) + lm] for i in range(outputs.shape[0])])
+
+
+def codebook_tables(centroids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """A11.  centroids (K, D) = cluster_centers_.  Returns (center_ (D,), centred (K, D))
+    (I_ea/loss_fn.py:10-14; C = cluster_centers_.T at I_ea/dataset/km_label.py:14)."""
+    c = centroids.float()
+    center = c.mean(dim=0)
+    return center, c - center[None, :]
+
+
+def codebook_argmax(values: torch.Tensor, centroids: torch.Tensor) -> torch.Tensor:
+    """A12.  pred = argmax_k cos(v, C_k - mean(C)); v is NOT centred (I_ea/loss_fn.py:44-47).
+    values (B, Lm, D) -> (B, Lm) int64."""
+    _, cc = codebook_tables(centroids)
+    flat = values.reshape(-1, values.shape[-1]).float()
+    sim = F.cosine_similarity(flat.unsqueeze(1), cc.unsqueeze(0), dim=-1)
+    return torch.argmax(sim, dim=1).view(values.shape[:-1])
+
+
+def splice_centroids(mel: torch.Tensor, labels: torch.Tensor, centroids: torch.Tensor, frame_pos: Sequence[int]) -> torch.Tensor:
+    """A13.  mel[b, :, pos:pos+Lm] = (centred[labels] + center_).T (I_ea/predict.py:184-187).  mel (B, D, Tm)."""
+    center, cc = codebook_tables(centroids)
+    out = mel.clone().float()
+    lm = labels.shape[1]
+    for b in range(mel.shape[0]):
+        p = int(frame_pos[b])
+        out[b, :, p:p + lm] = (cc[labels[b]] + center).T
+    return out
+
+
+# ----------------------------------------------------------------------------- A14
+def extend_mel(spec: torch.Tensor) -> torch.Tensor:
+    """A14.  Time-only bilinear stretch by 441/256, align_corners=False
+    (I_ea/hifi_gan/inference_modified.py:16-19).  (B, D, Tm) -> (B, D, floor(Tm*441/256)).
+    Restated without F.interpolate: src = fma(dst + 0.5, float(256/441), -0.5) clamped at 0, two-tap lerp."""
+    B, D, Tm = spec.shape
+    scale = 441 / 256
+    Tout = int(math.floor(float(Tm) * scale))
+    rscale = torch.tensor(1.0 / scale, dtype=torch.float32)                      # static_cast<float>(1.0 / scale)
+    dst = torch.arange(Tout, dtype=torch.float32)
+    # ATen evaluates scale * (dst + 0.5) - 0.5 as ONE fused multiply-add in fp32 (verified against
+    # F.interpolate bit patterns: a separate multiply loses up to 4e-6 of lambda near index 32+).
+    # The double product of two floats is exact, so rounding the double result once reproduces the fma.
+    src = ((dst + 0.5).double() * rscale.double() - 0.5).float().clamp(min=0.0)
+    i0 = src.floor().to(torch.int64).clamp_max(Tm - 1)
+    i1 = torch.clamp(i0 + 1, max=Tm - 1)
+    l1 = (src - i0.float()).clamp(0.0, 1.0)
+    l0 = 1.0 - l1
+    x = spec.float()
+    return l0 * x[:, :, i0] + l1 * x[:, :, i1]
+
+
+# ----------------------------------------------------------------------------- B1..B5 HiFi-GAN
+def get_padding(kernel_size: int, dilation: int = 1) -> int:
+    """I_ea/hifi_gan/utils.py:47-48."""
+    return int((kernel_size * dilation - dilation) / 2)
+
+
+def generator_forward(sd, arch, mel: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+    """B1..B4.  Generator.forward with ResBlock1 (I_ea/hifi_gan/models.py:107-123,36-43).
+    mel (B, 80, Tm') -> (B, 1, Tm'*hop) in (-1, 1).  Accepts folded or weight-normed state dicts (B5)."""
+    x = F.conv1d(mel.float(), _conv_weight(sd, "conv_pre"), sd["conv_pre.bias"].float(), padding=3)
+    nk = len(arch.resblock_kernel_sizes)
+    for i, (u, k) in enumerate(zip(arch.upsample_rates, arch.upsample_kernel_sizes)):
+        x = F.leaky_relu(x, LRELU_SLOPE)
+        x = F.conv_transpose1d(x, _conv_weight(sd, f"ups.{i}"), sd[f"ups.{i}.bias"].float(), stride=u, padding=(k - u) // 2)
+        if taps is not None:
+            taps[f"ups{i}"] = x
+        xs = None
+        for j, (rk, dil) in enumerate(zip(arch.resblock_kernel_sizes, arch.resblock_dilation_sizes)):
+            r = f"resblocks.{i * nk + j}."
+            y = x
+            for n, d in enumerate(dil):
+                t = F.leaky_relu(y, LRELU_SLOPE)
+                t = F.conv1d(t, _conv_weight(sd, f"{r}convs1.{n}"), sd[f"{r}convs1.{n}.bias"].float(),
+                             dilation=d, padding=get_padding(rk, d))
+                t = F.leaky_relu(t, LRELU_SLOPE)
+                t = F.conv1d(t, _conv_weight(sd, f"{r}convs2.{n}"), sd[f"{r}convs2.{n}.bias"].float(),
+                             padding=get_padding(rk, 1))
+                y = t + y
+            xs = y if xs is None else xs + y
+        x = xs / nk
+        if taps is not None:
+            taps[f"stage{i}"] = x
+    x = F.leaky_relu(x)                          # default slope 0.01 (models.py:119)
+    x = F.conv1d(x, _conv_weight(sd, "conv_post"), sd["conv_post.bias"].float(), padding=3)
+    return torch.tanh(x)
+
+
+def to_int16_pcm(audio: torch.Tensor):
+    """B6.  ``audio * 32768`` then numpy ``astype('int16')`` (truncation toward zero) (I_ea/predict.py:204-206)."""
+    return (audio * 32768.0).cpu().numpy().astype("int16")
+
+
+# ----------------------------------------------------------------------------- whole path
+def predict_batch(hubert_sd, harch, gen_sd, varch, centroids, wave16: torch.Tensor, mel: torch.Tensor,
+                  frame_pos: Sequence[int], frame_len: int, blind: bool = False, taps: Optional[dict] = None):
+    """The I_ea predict path for a batch (I_ea/predict.py:130-207, batch-ified).
+
+    wave16 (B, N) raw 16 kHz clips; mel (B, 80, Tm) log-mel of the (masked) 22.05 kHz clip;
+    frame_pos (B,) first masked 20 ms frame; frame_len Lm.  blind=True replaces every encoder frame
+    (mask_pos=0, mask_len=T).  Returns dict(feats, labels, mel, wave)."""
+    B = wave16.shape[0]
+    with torch.no_grad():
+        if blind:
+            starts, lens = [0] * B, [0] * B
+        else:
+            sl = [mask_samples_from_frames(int(p), frame_len) for p in frame_pos]
+            starts, lens = [s for s, _ in sl], [l for _, l in sl]
+        x = mask_and_normalize(wave16, starts, lens)
+        feats = custom_model_forward(hubert_sd, harch, x, taps)
+        T = feats.shape[1]
+        if blind:
+            pos, lm = [0] * B, min(T, mel.shape[2])
+        else:
+            pos, lm = [int(p) for p in frame_pos], frame_len
+        values = gather_masked_frames(feats, pos, lm)
+        labels = codebook_argmax(values, centroids)
+        mel2 = splice_centroids(mel, labels, centroids, pos)
+        wav = generator_forward(gen_sd, varch, extend_mel(mel2), taps)
+    return {"feats": feats, "labels": labels, "mel": mel2, "wave": wav[:, 0, :]}

@@ -1,0 +1,152 @@
+"""Architecture descriptors for the I_ea hot path.
+
+These are plain dataclasses holding the dimensions the native library needs.  They are
+filled either from a HuggingFace HuBERT ``config.json`` (the schema dumped in the
+reference at I_ea/dataset/config.json:62-124) and a HiFi-GAN ``config.json``
+(I_ea/hifi_gan/config_v1.json:1-37), or from the built-in presets below, which restate
+the two checkpoints the reference names (I_ea/model.py:26-31).
+"""
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass, field, asdict
+from typing import List, Tuple
+
+
+@dataclass
+class HubertArch:
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    conv_dim: Tuple[int, ...] = (512,) * 7
+    conv_kernel: Tuple[int, ...] = (10, 3, 3, 3, 3, 2, 2)
+    conv_stride: Tuple[int, ...] = (5, 2, 2, 2, 2, 2, 2)
+    conv_bias: bool = False
+    feat_extract_norm: str = "group"       # "group" (base) | "layer" (large)
+    do_stable_layer_norm: bool = False     # False: post-LN (base); True: pre-LN (large)
+    num_conv_pos_embeddings: int = 128
+    num_conv_pos_embedding_groups: int = 16
+    layer_norm_eps: float = 1e-5
+    feat_proj_layer_norm: bool = True
+    codebook_dim: int = 80                 # final_layers Linear(H -> codebook_dim), I_ea/model.py:75-78
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    def feat_lengths(self, n: int) -> List[int]:
+        """Conv-stack lengths [N, L1, ..., T] (formula: modeling_hubert.py:664-677)."""
+        out = [n]
+        for k, s in zip(self.conv_kernel, self.conv_stride):
+            n = (n - k) // s + 1
+            out.append(n)
+        return out
+
+    def num_frames(self, n: int) -> int:
+        return self.feat_lengths(n)[-1]
+
+    @classmethod
+    def base(cls) -> "HubertArch":
+        """facebook/hubert-base-ls960 (I_ea/model.py:28)."""
+        return cls()
+
+    @classmethod
+    def large(cls) -> "HubertArch":
+        """facebook/hubert-large-ls960-ft (I_ea/model.py:31)."""
+        return cls(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                   intermediate_size=4096, conv_bias=True, feat_extract_norm="layer",
+                   do_stable_layer_norm=True)
+
+    @classmethod
+    def tiny(cls, **kw) -> "HubertArch":
+        """Small shape used by fast parity tests (same code paths as base)."""
+        d = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                 intermediate_size=128, conv_dim=(32,) * 7,
+                 num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4,
+                 codebook_dim=80)
+        d.update(kw)
+        return cls(**d)
+
+    @classmethod
+    def from_hf_config(cls, cfg: dict, codebook_dim: int = 80) -> "HubertArch":
+        if cfg.get("model_type", "hubert") != "hubert":
+            raise ValueError(f"not a HuBERT config (model_type={cfg.get('model_type')!r})")
+        if cfg.get("feat_extract_activation", "gelu") != "gelu" or cfg.get("hidden_act", "gelu") != "gelu":
+            raise ValueError("only the erf-GELU activation of the reference checkpoints is supported")
+        if cfg.get("conv_pos_batch_norm", False):
+            raise ValueError("conv_pos_batch_norm checkpoints are not supported")
+        return cls(
+            hidden_size=cfg["hidden_size"], num_hidden_layers=cfg["num_hidden_layers"],
+            num_attention_heads=cfg["num_attention_heads"], intermediate_size=cfg["intermediate_size"],
+            conv_dim=tuple(cfg["conv_dim"]), conv_kernel=tuple(cfg["conv_kernel"]),
+            conv_stride=tuple(cfg["conv_stride"]), conv_bias=bool(cfg.get("conv_bias", False)),
+            feat_extract_norm=cfg.get("feat_extract_norm", "group"),
+            do_stable_layer_norm=bool(cfg.get("do_stable_layer_norm", False)),
+            num_conv_pos_embeddings=cfg.get("num_conv_pos_embeddings", 128),
+            num_conv_pos_embedding_groups=cfg.get("num_conv_pos_embedding_groups", 16),
+            layer_norm_eps=float(cfg.get("layer_norm_eps", 1e-5)),
+            feat_proj_layer_norm=bool(cfg.get("feat_proj_layer_norm", True)),
+            codebook_dim=codebook_dim)
+
+    @classmethod
+    def from_json(cls, path: str, codebook_dim: int = 80) -> "HubertArch":
+        with open(path) as f:
+            return cls.from_hf_config(json.load(f), codebook_dim)
+
+
+@dataclass
+class VocoderArch:
+    """HiFi-GAN generator hyper-parameters (I_ea/hifi_gan/config_v1.json:2,11-15)."""
+    resblock: str = "1"
+    upsample_rates: Tuple[int, ...] = (8, 8, 2, 2)
+    upsample_kernel_sizes: Tuple[int, ...] = (16, 16, 4, 4)
+    upsample_initial_channel: int = 512
+    resblock_kernel_sizes: Tuple[int, ...] = (3, 7, 11)
+    resblock_dilation_sizes: Tuple[Tuple[int, ...], ...] = ((1, 3, 5),) * 3
+    num_mels: int = 80
+    sampling_rate: int = 22050
+
+    @property
+    def hop(self) -> int:
+        h = 1
+        for u in self.upsample_rates:
+            h *= u
+        return h
+
+    @classmethod
+    def v1(cls) -> "VocoderArch":
+        return cls()
+
+    @classmethod
+    def tiny(cls) -> "VocoderArch":
+        return cls(upsample_initial_channel=64)
+
+    @classmethod
+    def from_config(cls, h: dict) -> "VocoderArch":
+        if str(h.get("resblock", "1")) != "1":
+            raise ValueError("only ResBlock1 generators (config_v1/v2) are implemented; "
+                             "config_v3 (ResBlock2) is not on the I_ea predict path (predict.yaml:35)")
+        return cls(resblock=str(h.get("resblock", "1")),
+                   upsample_rates=tuple(h["upsample_rates"]),
+                   upsample_kernel_sizes=tuple(h["upsample_kernel_sizes"]),
+                   upsample_initial_channel=int(h["upsample_initial_channel"]),
+                   resblock_kernel_sizes=tuple(h["resblock_kernel_sizes"]),
+                   resblock_dilation_sizes=tuple(tuple(d) for d in h["resblock_dilation_sizes"]),
+                   num_mels=int(h.get("num_mels", 80)),
+                   sampling_rate=int(h.get("sampling_rate", 22050)))
+
+
+EXTEND_NUM, EXTEND_DEN = 441, 256   # extend_mel scale 441/256 (I_ea/hifi_gan/inference_modified.py:17)
+
+
+def mel_frames(n22: int, n_fft: int = 1024, hop: int = 441) -> int:
+    """Mel frame count of get_mel (I_ea/dataset/mel_dump.py:75,78-87): reflect pad (n_fft-hop)/2 each side."""
+    pad = (n_fft - hop) // 2
+    return (n22 + 2 * pad - n_fft) // hop + 1
+
+
+def extended_frames(tm: int) -> int:
+    """Output width of extend_mel: floor(Tm * 441/256) (F.interpolate with scale_factor)."""
+    import math
+    return int(math.floor(float(tm) * (EXTEND_NUM / EXTEND_DEN)))

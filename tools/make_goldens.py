@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE's own modules (authoring container only).
+
+The reference ships no tests or golden vectors for the predict path, so the oracle
+(oracle/ref_cpu.py) and the HIP path are pinned against outputs of the reference itself, run here on CPU:
+
+* ``I_ea/model.py::CustomModel.forward`` over a locally constructed ``transformers.HubertModel`` (the
+  constructor cannot run offline: it calls ``from_pretrained`` on a model NAME, I_ea/model.py:32,39, so the
+  instance is assembled with ``__new__`` exactly as ``__init__`` lines 40,75-78 would);
+* ``transformers.Wav2Vec2FeatureExtractor`` (the class behind ``AutoProcessor`` at I_ea/predict.py:136);
+* ``I_ea/loss_fn.py::LossFunction`` + ``I_ea/dataset/km_label.py::ApplyKmeans`` on a synthetic joblib ``.km``;
+* ``I_ea/hifi_gan/models.py::Generator``;
+* ``extend_mel``: its module (I_ea/hifi_gan/inference_modified.py) imports librosa at the top, which is
+  absent here, and no stand-in is written for it; the function body is one ``F.interpolate`` call
+  (lines 17-19), which ``_extend_mel_call`` below issues with the same arguments, so the arithmetic that
+  produces the fixture is still torch's own interpolate kernel, not the oracle's restatement.
+
+The reference imports itself as package ``Inpainting`` (I_ea/predict.py:13,16), which does not exist in
+the tree; a scratch symlink ``Inpainting -> /root/reference/I_ea`` under /tmp provides that name.  Nothing
+of the reference's source is copied; only numbers are written.  Weights/inputs come from
+speech_inpainting_amd.synth (seeded), so tests can rebuild them without the reference.
+
+usage: python tools/make_goldens.py [--out tests/golden]
+"""
+import argparse
+import hashlib
+import importlib.machinery
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from speech_inpainting_amd import synth                     # noqa: E402
+from speech_inpainting_amd.arch import HubertArch, VocoderArch  # noqa: E402
+
+
+def _expose_reference():
+    sys.dont_write_bytecode = True
+    shim = tempfile.mkdtemp(prefix="refshim_")
+    os.symlink(os.path.join(REF, "I_ea"), os.path.join(shim, "Inpainting"))
+    sys.path.insert(0, shim)
+    import transformers  # noqa: F401  (must be imported before the soundfile stub)
+    from transformers import HubertModel  # noqa: F401
+    sf = types.ModuleType("soundfile")
+    sf.__spec__ = importlib.machinery.ModuleSpec("soundfile", None)
+    sys.modules.setdefault("soundfile", sf)
+
+
+def _hf_config(arch: HubertArch):
+    from transformers import HubertConfig
+    return HubertConfig(
+        hidden_size=arch.hidden_size, num_hidden_layers=arch.num_hidden_layers,
+        num_attention_heads=arch.num_attention_heads, intermediate_size=arch.intermediate_size,
+        conv_dim=list(arch.conv_dim), conv_kernel=list(arch.conv_kernel), conv_stride=list(arch.conv_stride),
+        conv_bias=arch.conv_bias, feat_extract_norm=arch.feat_extract_norm,
+        do_stable_layer_norm=arch.do_stable_layer_norm,
+        num_conv_pos_embeddings=arch.num_conv_pos_embeddings,
+        num_conv_pos_embedding_groups=arch.num_conv_pos_embedding_groups,
+        layer_norm_eps=arch.layer_norm_eps, attn_implementation="eager")
+
+
+def build_reference_custom_model(arch: HubertArch, sd):
+    """CustomModel assembled without __init__ (which would fetch), then the reference's own forward is used."""
+    import torch.nn as nn
+    from transformers import HubertModel
+    from Inpainting.model import CustomModel
+    m = CustomModel.__new__(CustomModel)
+    nn.Module.__init__(m)
+    m.base_model = HubertModel(_hf_config(arch))
+    m.last_hidden_dim = arch.hidden_size
+    m.final_layers = nn.Sequential(nn.LayerNorm(arch.hidden_size), nn.Linear(arch.hidden_size, arch.codebook_dim))
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith("masked_spec_embed") for k in missing), missing
+    return m.eval()
+
+
+def build_reference_generator(varch: VocoderArch, sd):
+    from Inpainting.hifi_gan.models import Generator
+    from Inpainting.hifi_gan.env import AttrDict
+    h = AttrDict(dict(resblock=varch.resblock, upsample_rates=list(varch.upsample_rates),
+                      upsample_kernel_sizes=list(varch.upsample_kernel_sizes),
+                      upsample_initial_channel=varch.upsample_initial_channel,
+                      resblock_kernel_sizes=list(varch.resblock_kernel_sizes),
+                      resblock_dilation_sizes=[list(d) for d in varch.resblock_dilation_sizes]))
+    g = Generator(h)
+    g.load_state_dict(sd)            # un-folded weight_g/weight_v form, as predict.py:119
+    g.eval()
+    g.remove_weight_norm()           # predict.py:122
+    return g
+
+
+def build_reference_loss(centroids: torch.Tensor, tmpdir: str):
+    import joblib
+    from sklearn.cluster import MiniBatchKMeans
+    from Inpainting.loss_fn import LossFunction
+    km = MiniBatchKMeans(n_clusters=centroids.shape[0])
+    km.cluster_centers_ = centroids.numpy().astype(np.float32)
+    path = os.path.join(tmpdir, "model.km")
+    joblib.dump(km, path)
+    return LossFunction(path, device="cpu")
+
+
+def _extend_mel_call(spec: torch.Tensor) -> torch.Tensor:
+    """The F.interpolate call of I_ea/hifi_gan/inference_modified.py:17-19 (see module docstring)."""
+    import torch.nn.functional as F
+    return F.interpolate(spec.unsqueeze(0), scale_factor=(1, 441 / 256), mode="bilinear",
+                         align_corners=False).squeeze(0)
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
+
+
+def rms(t):
+    return float(t.float().pow(2).mean().sqrt())
+
+
+def run_case(name, harch, varch, B, N, frame_pos, lm, K, out_dir, tmpdir, store_wave=True, blind=False,
+             legacy_pos=False):
+    from transformers import Wav2Vec2FeatureExtractor
+    extend_mel = _extend_mel_call
+    seed = synth.DEFAULT_SEED
+    hsd = synth.synth_hubert_state(harch, seed, "legacy" if legacy_pos else "parametrizations")
+    hsd_ref = hsd
+    if legacy_pos:  # the installed torch only knows the parametrizations names; values are identical
+        hsd_ref = synth.synth_hubert_state(harch, seed, "parametrizations")
+    gsd = synth.synth_generator_state(varch, seed + 1)
+    cb = synth.synth_codebook(K, 80, seed + 2)
+    wave = synth.synth_wave(B, N, seed + 3)
+    T = harch.num_frames(N)
+    n22 = N * 22050 // 16000
+    from speech_inpainting_amd.arch import mel_frames
+    Tm = mel_frames(n22)
+    mel = synth.synth_mel(B, Tm, 80, seed + 4)
+
+    model = build_reference_custom_model(harch, hsd_ref)
+    gen = build_reference_generator(varch, gsd)
+    loss = build_reference_loss(cb, tmpdir)
+    proc = Wav2Vec2FeatureExtractor(feature_size=1, sampling_rate=16000, padding_value=0.0,
+                                    do_normalize=True, return_attention_mask=True)
+    with torch.no_grad():
+        feats_all, x_norm_all = [], []
+        for b in range(B):   # the reference runs batch 1 (predict.py:151-163); clips are independent
+            w = wave[b].numpy().copy()
+            if not blind:
+                p = int(frame_pos[b])
+                w[p * 320 + 80:(p + lm) * 320 + 79 - 80] = 0                 # predict.py:133
+            tok = proc(w, sampling_rate=16000, return_attention_mask=True, return_tensors="pt")
+            x_norm_all.append(tok.input_values[0])
+            feats_all.append(model(tok.input_values, tok.attention_mask)[0])  # predict.py:163
+        feats = torch.stack(feats_all)
+        if blind:
+            pos = [0] * B
+            lm_eff = min(T, Tm)
+        else:
+            pos = [int(p) for p in frame_pos]
+            lm_eff = lm
+        values = torch.zeros((B, lm_eff, feats.shape[-1]))
+        for i in range(B):
+            values[i] = feats[i, pos[i]:pos[i] + lm_eff]                      # predict.py:164-168
+        dummy = torch.zeros((B, lm_eff), dtype=torch.int64)
+        _, pred = loss.cos_sim(values, dummy)                                 # predict.py:171
+        mel2 = mel.clone()
+        for i in range(B):
+            pm = loss.all_embeds_t_c[0, pred[i, :], :] + loss.center_        # predict.py:184-185
+            mel2[i, :, pos[i]:pos[i] + lm_eff] = pm.T                         # predict.py:187
+        ext = torch.cat([extend_mel(mel2[i:i + 1]) for i in range(B)])            # predict.py:189
+        wav = gen(ext)[:, 0, :]                                               # predict.py:203
+    rec = dict(
+        meta=json.dumps(dict(name=name, B=B, N=N, T=T, Tm=Tm, lm=lm_eff, K=K, blind=blind, seed=seed,
+                             legacy_pos=legacy_pos, harch=harch.__dict__, varch=varch.__dict__,
+                             torch=torch.__version__), default=list),
+        frame_pos=np.asarray(pos, np.int32),
+        x_norm_head=torch.stack(x_norm_all)[:, :64].numpy(),
+        x_norm_sha=np.frombuffer(bytes.fromhex(sha(torch.stack(x_norm_all))), np.uint8),
+        feats=feats.numpy(), labels=pred.numpy().astype(np.int64),
+        mel_spliced=mel2.numpy(), ext_sha=np.frombuffer(bytes.fromhex(sha(ext)), np.uint8),
+        wave_rms=np.float64(rms(wav)), wave_absmax=np.float64(float(wav.abs().max())),
+        weight_probe=np.asarray([float(hsd["final_layers.1.weight"][0, 0]), float(gsd["conv_post.weight_v"][0, 0, 0]),
+                                 float(cb[0, 0]), float(wave[0, 100]), float(mel[0, 0, 0])], np.float64),
+    )
+    if store_wave:
+        rec["wave"] = wav.numpy()
+    else:
+        rec["wave_head"] = wav[:, :2048].numpy()
+        rec["wave_tail"] = wav[:, -2048:].numpy()
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+    print(f"{name}: feats rms {rms(feats):.4f}  wave rms {rms(wav):.4f} absmax {float(wav.abs().max()):.3f}  "
+          f"labels[0][:10] {pred[0][:10].tolist()}")
+
+
+def extend_cases(out_dir):
+    extend_mel = _extend_mel_call
+    rec = {}
+    g = torch.Generator().manual_seed(7)
+    for tm in (1, 2, 3, 7, 64, 200, 373, 500):
+        x = torch.randn(6, tm, generator=g)           # rows are independent; 6 suffice
+        rec[f"in_{tm}"] = x.numpy()
+        rec[f"out_{tm}"] = extend_mel(x[None])[0].numpy()   # reference passes (1, 80, Tm)
+    np.savez_compressed(os.path.join(out_dir, "extend_mel.npz"), **rec)
+    print("extend_mel: widths", {k: v.shape[-1] for k, v in rec.items() if k.startswith("out_")})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    _expose_reference()
+    tmp = tempfile.mkdtemp(prefix="goldens_")
+    cases = {
+        # config #1: 1 x 4 s clip, 200 ms mask, base + V1 (BASELINE.json configs[0])
+        "base_4s": lambda: run_case("base_4s", HubertArch.base(), VocoderArch.v1(), 1, 64000, [90], 10, 100, a.out, tmp),
+        # config #4 encoder: HuBERT-large, 400 ms mask; waveform stored as head/tail only
+        "large_4s": lambda: run_case("large_4s", HubertArch.large(), VocoderArch.v1(), 1, 64000, [90], 20, 100, a.out, tmp,
+                                     store_wave=False),
+        # small shapes for fast CPU/GPU parity: ragged clip length, masks at both ends, K=500, legacy key names
+        "tiny_group": lambda: run_case("tiny_group", HubertArch.tiny(), VocoderArch.tiny(), 3, 8170, [0, 11, 15], 10, 100, a.out, tmp),
+        "tiny_layer": lambda: run_case("tiny_layer", HubertArch.tiny(conv_bias=True, feat_extract_norm="layer",
+                                                                     do_stable_layer_norm=True),
+                                       VocoderArch.tiny(), 2, 6400, [3, 9], 5, 500, a.out, tmp, legacy_pos=True),
+        "tiny_blind": lambda: run_case("tiny_blind", HubertArch.tiny(), VocoderArch.tiny(), 2, 8000, [0, 0], 0, 100, a.out, tmp,
+                                       blind=True),
+        "extend_mel": lambda: extend_cases(a.out),
+    }
+    for k, fn in cases.items():
+        if a.only and k not in a.only.split(","):
+            continue
+        fn()
+
+
+if __name__ == "__main__":
+    main()

@@ -140,9 +140,11 @@ class VocoderArch:
 EXTEND_NUM, EXTEND_DEN = 441, 256   # extend_mel scale 441/256 (I_ea/hifi_gan/inference_modified.py:17)
 
 
-def mel_frames(n22: int, n_fft: int = 1024, hop: int = 441) -> int:
-    """Mel frame count of get_mel (I_ea/dataset/mel_dump.py:75,78-87): reflect pad (n_fft-hop)/2 each side."""
-    pad = (n_fft - hop) // 2
+MEL_PAD = 312   # padd_ of I_ea/dataset/mel_dump.py:15 (NOT (n_fft - hop) / 2 = 291, which is commented out at :71)
+
+
+def mel_frames(n22: int, n_fft: int = 1024, hop: int = 441, pad: int = MEL_PAD) -> int:
+    """Mel frame count of get_mel (I_ea/dataset/mel_dump.py:72,75-87): reflect-pad 312 each side, STFT center=False."""
     return (n22 + 2 * pad - n_fft) // hop + 1
 
 

@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Benchmark of the I_ea predict hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one resident batch of synthetic clips: masked 16 kHz waveforms ->
+HuBERT-base encoder -> LN+Linear head -> codeword arg-max + mel splice -> x441/256 stretch -> HiFi-GAN V1 ->
+waveforms.  Workload at every N: BASELINE.json configs[1] per GPU (batch 32 x 4 s clips, 200 ms mask, HuBERT-base
+encoder GEMMs on bf16 MFMA with fp32 accumulate, fp32 vocoder); at N > 1 utterances are sharded, 32 per rank
+(configs[2] at N = 8), weights arrive by one RCCL broadcast, metrics by one all-gather.  Inputs and weights are in HBM
+before the timed region; outputs stay in HBM.
+
+Prints ONE JSON line on rank 0 (metric/value/... plus `roofline` for the dominant kernel family, measured with HIP
+events inside the timed region, and `cpu_baseline`: the CPU oracle timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+CLIP_SECONDS = 4.0
+N_SAMPLES = 64000
+MASK_FRAMES = 10          # 200 ms
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_HBM_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def family_math(name: str) -> str:
+    for m in ("bf16x3", "bf16", "f32"):
+        if f"_{m}" in name:
+            return m
+    return "f32"
+
+
+def cpu_baseline(batch: int):
+    """The CPU oracle (plain torch fp32 restatement of the reference) on this host's cores; bounded sample."""
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch, mel_frames
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    harch, varch = HubertArch.base(), VocoderArch.v1()
+    hsd, gsd, cb = synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook()
+    Tm = mel_frames(N_SAMPLES * 22050 // 16000)
+    wave, mel = synth.synth_wave(batch, N_SAMPLES), synth.synth_mel(batch, Tm)
+    pos = synth.synth_mask_frames(batch, harch.num_frames(N_SAMPLES), MASK_FRAMES).tolist()
+    R.predict_batch(hsd, harch, gsd, varch, cb, wave[:1], mel[:1], pos[:1], MASK_FRAMES)      # warm-up
+    t0 = time.perf_counter()
+    R.predict_batch(hsd, harch, gsd, varch, cb, wave, mel, pos, MASK_FRAMES)
+    dt = time.perf_counter() - t0
+    return {"value": batch * CLIP_SECONDS / dt, "unit": "x real-time (audio-sec/wall-sec)", "cores": cores, "kind": "port",
+            "sample": f"{batch} of the same 4 s clips, one pass, fp32, torch CPU oracle (oracle/ref_cpu.py), {dt:.2f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--encoder-dtype", default="bf16", choices=["fp32", "bf16", "bf16x3"])
+    ap.add_argument("--vocoder-dtype", default="fp32", choices=["fp32", "bf16", "bf16x3"])
+    ap.add_argument("--vocoder-chunk", type=int, default=0)
+    ap.add_argument("--cpu-clips", type=int, default=8, help="clips timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    a = ap.parse_args()
+
+    from speech_inpainting_amd import parallel, synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch, mel_frames
+    from speech_inpainting_amd.engine import InpaintingEngine
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    rank, local_rank, world = parallel.init_distributed("nccl")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    harch, varch = HubertArch.base(), VocoderArch.v1()
+    K = 100
+    B = a.batch
+    T = harch.num_frames(N_SAMPLES)
+    Tm = mel_frames(N_SAMPLES * 22050 // 16000)
+
+    t_load = time.perf_counter()
+    eng = parallel.setup_engine(
+        lambda: InpaintingEngine(harch, varch, K, dev, a.encoder_dtype, a.vocoder_dtype, a.vocoder_chunk),
+        lambda: (synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook(K)),
+        rank)
+    # this rank's slice of the global utterance list (seeded per global clip index)
+    lo, hi = parallel.shard_range(B * world, rank, world)
+    wave = synth.synth_wave(hi - lo, N_SAMPLES, synth.DEFAULT_SEED + 3 + lo).to(dev)
+    mel = synth.synth_mel(hi - lo, Tm, 80, synth.DEFAULT_SEED + 4 + lo).to(dev)
+    pos = synth.synth_mask_frames(hi - lo, T, MASK_FRAMES, synth.DEFAULT_SEED + 5 + lo).to(dev)
+    mstart = (pos * 320 + 80).to(torch.int32)
+    mlen = torch.full_like(pos, MASK_FRAMES * 320 - 81)
+    torch.cuda.synchronize()
+    if rank == 0:
+        log(f"[bench] setup {time.perf_counter() - t_load:.1f} s; B={B}/GPU x {world} GPU, T={T}, Tm={Tm}, "
+            f"encoder {a.encoder_dtype}, vocoder {a.vocoder_dtype}")
+
+    def step():
+        return eng.predict_batch(wave, mel, pos, MASK_FRAMES, mask_start=mstart, mask_len=mlen)
+
+    for _ in range(a.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    events = not a.no_kernel_events
+    if events:
+        eng.ctx.profile_start(600 * max(a.steps, 1))
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.ctx.profile_stop() if events else []
+
+    wav = out["wave"]
+    finite = bool(torch.isfinite(wav).all())
+    stats = parallel.gather_metrics([elapsed, float(hi - lo), float(wav.pow(2).mean().sqrt()), float(finite)], dev).cpu()
+    if rank != 0:
+        return
+    elapsed_max = float(stats[:, 0].max())
+    clips = float(stats[:, 1].sum())
+    if not bool(stats[:, 3].min()):
+        raise SystemExit("non-finite samples in the output waveform")
+    value = clips * a.steps * CLIP_SECONDS / elapsed_max
+
+    res = {
+        "metric": "real-time factor (audio-sec/wall-sec), 4 s clips @16 kHz, 200 ms mask",
+        "value": round(value, 2), "unit": "x real-time (audio-sec/wall-sec), whole job",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * elapsed_max / a.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": f"encoder GEMMs {a.encoder_dtype} MFMA (fp32 accumulate; attention, head, arg-max fp32), vocoder {a.vocoder_dtype}",
+        "data": "synthetic (seeded clips, random-init weights of the HuBERT-base + HiFi-GAN V1 architecture)",
+        "config": {"workload": "BASELINE configs[1]: batch=32 x 4 s clips per GPU, 200 ms mask, HuBERT-base + HiFi-GAN V1"
+                               + ("" if world == 1 else f", utterance-sharded over {world} GPUs (configs[2] at 8)"),
+                   "global_batch": int(clips), "clip_samples": N_SAMPLES, "mask_frames": MASK_FRAMES,
+                   "parallelism": f"utterance-sharded x{world}", "output_rms": round(float(stats[0, 2]), 4)},
+        "clips_per_s": round(clips * a.steps / elapsed_max, 2),
+        "gflop_per_clip_algorithmic": 268.3,
+        "achieved_tflops_whole_path": round(268.3e9 * clips * a.steps / elapsed_max / 1e12, 2),
+    }
+    if prof:
+        prof.sort(key=lambda e: -e["ms"])
+        tot = sum(e["ms"] for e in prof)
+        log(f"[bench] per-kernel HIP-event time (rank 0, {a.steps} steps): {tot / a.steps:.2f} ms/step in kernels")
+        for e in prof:
+            log(f"    {e['name']:<28} {e['launches'] / a.steps:7.1f} launches/step {e['ms'] / a.steps:9.3f} ms/step "
+                f"{e['flops'] / e['ms'] / 1e9 if e['ms'] else 0:8.2f} TFLOP/s {e['bytes'] / e['ms'] / 1e6 if e['ms'] else 0:9.1f} GB/s (algorithmic)")
+        d = prof[0]
+        m = family_math(d["name"])
+        avg_ms = d["ms"] / d["launches"]
+        ach = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+        res["roofline"] = {"bound": "mfma", "kernel": d["name"], "achieved": round(ach, 2), "peak": PEAK_TFLOPS[m],
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[m], 4), "traffic": None,
+                           "avg_launch_ms": round(avg_ms, 4), "launches_per_step": round(d["launches"] / a.steps, 1),
+                           "share_of_kernel_time": round(d["ms"] / tot, 3),
+                           "flops_per_launch": d["flops"] / d["launches"]}
+        res["kernel_families"] = [{"name": e["name"], "ms_per_step": round(e["ms"] / a.steps, 3),
+                                   "tflops": round(e["flops"] / e["ms"] / 1e9, 2) if e["ms"] else 0.0,
+                                   "gbs": round(e["bytes"] / e["ms"] / 1e6, 1) if e["ms"] else 0.0} for e in prof[:8]]
+    if world == 1 and a.cpu_clips > 0:
+        try:
+            res["cpu_baseline"] = cpu_baseline(a.cpu_clips)
+        except Exception as ex:     # the oracle is a checker; its absence must not void the GPU number
+            res["cpu_baseline"] = {"error": repr(ex)}
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+/*
+ * si_hip.h -- C ABI of libsi_hip.so: the MI355X (gfx950) implementation of the I_ea predict hot path.
+ *
+ * The reference (Fireflies-17/Speech-Inpainting) has no FFI; its seam is three Python module calls.
+ * Each entry point below replaces one of them (paths relative to /root/reference):
+ *
+ *   si_hubert_forward    <- CustomModel.forward                I_ea/model.py:80-89 (called at I_ea/predict.py:163)
+ *                           + the zero-mask + processor normalise in front of it (I_ea/predict.py:132-141)
+ *   si_codebook_splice   <- frame gather + LossFunction.cos_sim arg-max + centroid splice
+ *                           I_ea/predict.py:164-168,171,184-187 ; I_ea/loss_fn.py:44-47
+ *   si_hifigan_forward   <- extend_mel + Generator.forward     I_ea/hifi_gan/inference_modified.py:16-19 ;
+ *                           I_ea/hifi_gan/models.py:107-123 (called at I_ea/predict.py:189,203)
+ *   si_load_weights      <- model.load_state_dict / generator.load_state_dict + remove_weight_norm + ApplyKmeans
+ *                           I_ea/predict.py:117-122,149 ; I_ea/hifi_gan/models.py:125-132 ; I_ea/dataset/km_label.py:12-24
+ *
+ * Conventions: plain C types only; every function returns 0 on success and a negative SI_E* code on
+ * failure (message via si_last_error); no exceptions cross the boundary.  A context is bound to one device,
+ * is not thread-safe, enqueues all work on the caller's HIP stream and never synchronises it.  All data
+ * pointers are DEVICE pointers owned by the caller unless the parameter says "host".
+ * Activations are fp32.  Layouts are the reference's: wave (B, N); feats (B, T, D); mel (B, D, Tm)
+ * channels-first; waveform (B, Tm' * hop).
+ */
+#ifndef SI_HIP_H
+#define SI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SI_ABI_VERSION 1
+
+enum {
+    SI_OK = 0,
+    SI_EINVAL = -1,      /* bad argument / unsupported shape */
+    SI_ENOMEM = -2,      /* workspace too small or device allocation failed */
+    SI_EHIP = -3,        /* a HIP runtime call failed */
+    SI_ESTATE = -4,      /* call order violated (e.g. forward before weights) */
+    SI_EWEIGHTS = -5     /* missing / mis-shaped tensor in the checkpoint index */
+};
+
+/* arithmetic of the contraction (accumulation is always fp32) */
+enum {
+    SI_MATH_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 fma chain */
+    SI_MATH_BF16 = 1,    /* v_mfma_f32_32x32x16_bf16, operands rounded to bf16 */
+    SI_MATH_BF16X3 = 2   /* hi/lo split bf16, 3 MFMAs per product: ~2^-16 relative operand error */
+};
+
+#define SI_MAX_CONV 8
+#define SI_MAX_UPS 8
+#define SI_MAX_RB 4
+#define SI_MAX_DIL 4
+
+typedef struct si_ctx si_ctx;
+typedef void* si_stream_t;      /* hipStream_t */
+
+/* Architecture + arithmetic of one model pair.  HuBERT fields follow the HuggingFace config.json
+ * (I_ea/dataset/config.json:62-124), vocoder fields the HiFi-GAN json (I_ea/hifi_gan/config_v1.json). */
+typedef struct si_model_desc {
+    int32_t struct_size;            /* = sizeof(si_model_desc), ABI check */
+    /* encoder */
+    int32_t hidden_size, num_layers, num_heads, intermediate_size;
+    int32_t num_conv;
+    int32_t conv_dim[SI_MAX_CONV], conv_kernel[SI_MAX_CONV], conv_stride[SI_MAX_CONV];
+    int32_t conv_bias;              /* 0 base / 1 large */
+    int32_t feat_norm_layer;        /* 0 = "group" (GroupNorm on conv0 only), 1 = "layer" (LayerNorm on every conv) */
+    int32_t stable_layer_norm;      /* 0 post-LN (base), 1 pre-LN (large) */
+    int32_t pos_conv_kernel, pos_conv_groups;
+    int32_t feat_proj_layer_norm;
+    float   layer_norm_eps;
+    int32_t codebook_dim;           /* final_layers Linear(H -> codebook_dim), 80 */
+    int32_t num_clusters;           /* K centroids, 100 or 500 */
+    /* vocoder (ResBlock1 generators) */
+    int32_t num_mels;
+    int32_t num_ups;
+    int32_t up_rates[SI_MAX_UPS], up_kernels[SI_MAX_UPS];
+    int32_t up_initial_channel;
+    int32_t num_rb;                 /* resblocks per stage (3) */
+    int32_t rb_kernels[SI_MAX_RB];
+    int32_t num_dil;                /* dilations per resblock (3) */
+    int32_t rb_dilations[SI_MAX_RB][SI_MAX_DIL];
+    /* arithmetic */
+    int32_t encoder_math;           /* SI_MATH_* for the encoder GEMMs/convs (attention + head stay fp32) */
+    int32_t vocoder_math;           /* SI_MATH_* for the generator convs */
+    int32_t vocoder_chunk;          /* clips per vocoder pass (0 = library default; sized to the Infinity Cache) */
+} si_model_desc;
+
+int si_version(void);
+
+/* Create a context on `device_id`.  No device memory is allocated until weights are loaded. */
+int si_create(si_ctx** out, int device_id, const si_model_desc* desc);
+void si_destroy(si_ctx* ctx);
+
+/* Last error text of this context (or of si_create when ctx == NULL).  Never NULL. */
+const char* si_last_error(const si_ctx* ctx);
+
+/* Load a checkpoint.  `host_blob` (host memory) holds fp32 tensors; `index` is text, one tensor per line:
+ *     <name> <byte_offset> <ndim> <d0> ... <d(ndim-1)>
+ * Names are the reference's state-dict keys: "base_model.<hf key>", "final_layers.{0,1}.{weight,bias}",
+ * "generator.<Generator key>" (folded ".weight" or weight-norm ".weight_g"/".weight_v"), "codebook" (K, D).
+ * Weight-norm is folded here (dim 0 for the generator, dim 2 for the positional conv, in either the
+ * "parametrizations.weight.original{0,1}" or the legacy "weight_g/weight_v" spelling).  The tensors are
+ * re-laid-out for the kernels into one packed device blob owned by the context. */
+int si_load_weights(si_ctx* ctx, const void* host_blob, size_t nbytes, const char* index);
+
+/* Multi-GPU: ranks that do not read the checkpoint allocate the (identically laid out) packed blob with
+ * si_alloc_weights and receive its bytes by an RCCL broadcast into si_weights_device_ptr. */
+int si_alloc_weights(si_ctx* ctx);
+int si_weights_device_ptr(si_ctx* ctx, void** ptr, size_t* nbytes);
+
+/* Workspace (device scratch) needed for a batch of B clips of N samples and Tm mel frames. */
+int si_workspace_bytes(si_ctx* ctx, int B, int N, int Tm, size_t* out);
+
+/* Encoder: 16 kHz clips -> (B, T, codebook_dim).  Samples [mask_start[b], mask_start[b]+mask_len[b])
+ * are zeroed, then (normalize != 0) each clip is normalised to zero mean / unit variance (eps 1e-7); both are
+ * fused into the load of the first conv.  normalize = 0 takes `wav` as the processor's input_values
+ * (already normalised), which is what CustomModel.forward receives in the reference.
+ * mask_start / mask_len: device int32 (B), may be NULL (no mask).
+ * T = the conv-stack length of N (modeling_hubert.py:664-677). */
+int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len, int normalize,
+                      int B, int N, float* out_feats, void* workspace, size_t workspace_bytes, si_stream_t stream);
+
+/* Codeword decision + splice: for b, j < Lm:  label = argmax_k cos(feats[b, pos_b + j], C_k - mean(C));
+ * mel[b, :, pos_b + j] = C_label.   feats (B, T, D); frame_pos device int32 (B); mel (B, D, Tm) in/out;
+ * labels device int64 (B, Lm), may be NULL. */
+int si_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, const int32_t* frame_pos, int Lm,
+                       float* mel, int Tm, int64_t* labels, si_stream_t stream);
+
+/* Vocoder: mel (B, D, Tm) -> time-stretch x441/256 -> generator -> wav_out (B, floor(Tm*441/256) * hop).
+ * stretch = 0 skips extend_mel (mel already at the generator's frame rate; output (B, Tm * hop)). */
+int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch, float* wav_out,
+                       void* workspace, size_t workspace_bytes, si_stream_t stream);
+
+/* Shape helpers (host arithmetic only). */
+int si_num_frames(const si_ctx* ctx, int N);            /* encoder frames T for N samples, <0 on error */
+int si_vocoder_samples(const si_ctx* ctx, int Tm, int stretch);   /* output samples per clip */
+
+/* Per-kernel timing.  Between si_profile_start and si_profile_stop every kernel launch of this context is
+ * bracketed by two HIP events recorded on the launch stream.  si_profile_stop waits for those events and returns
+ * one entry per kernel family: launches, summed device milliseconds, summed ALGORITHMIC flops and bytes (layer
+ * shapes only: no padding, halo or recompute).  max_launches bounds the event pool; launches beyond it are not
+ * recorded.  This is what bench.py's `roofline` object is computed from. */
+typedef struct si_profile_entry {
+    char name[48];
+    int32_t launches;
+    int32_t reserved;
+    double ms;
+    double flops;
+    double bytes;
+} si_profile_entry;
+int si_profile_start(si_ctx* ctx, int max_launches);
+int si_profile_stop(si_ctx* ctx, si_profile_entry* out, int capacity, int* count);
+
+/* Test hook.  Intermediates are named "features", "projected", "encoder_in", "last_hidden" (encoder) and
+ * "ups<i>", "stage<i>" (vocoder; of the last chunk of clips).  si_debug_capture registers a device buffer that
+ * the NEXT forwards copy the named tensor into at the moment it is produced (workspace buffers are recycled
+ * within a forward); dst = NULL unregisters.  si_debug_size returns the tensor's float count in the last forward. */
+int si_debug_capture(si_ctx* ctx, const char* name, float* dst, long capacity);
+long si_debug_size(si_ctx* ctx, const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SI_HIP_H */

@@ -61,8 +61,8 @@ class HubertArch:
     @classmethod
     def tiny(cls, **kw) -> "HubertArch":
         """Small shape used by fast parity tests (same code paths as base)."""
-        d = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
-                 intermediate_size=128, conv_dim=(32,) * 7,
+        d = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                 intermediate_size=256, conv_dim=(32,) * 7,
                  num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4,
                  codebook_dim=80)
         d.update(kw)
@@ -120,7 +120,7 @@ class VocoderArch:
 
     @classmethod
     def tiny(cls) -> "VocoderArch":
-        return cls(upsample_initial_channel=64)
+        return cls(upsample_initial_channel=256)
 
     @classmethod
     def from_config(cls, h: dict) -> "VocoderArch":

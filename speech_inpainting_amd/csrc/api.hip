@@ -1,0 +1,886 @@
+// api.hip -- C ABI of libsi_hip.so (include/si_hip.h): context, checkpoint packing, forward orchestration.
+//
+// Host-side work done here, once per checkpoint load:
+//   * weight-norm folding, w = g * v / ||v||  (generator convs: norm over all dims but 0,
+//     I_ea/hifi_gan/models.py:125-132; positional conv: over all dims but 2, modeling_hubert.py:78)
+//   * re-layout of every Conv1d / ConvTranspose1d / Linear weight into the tap-GEMM form
+//     W[group][tap][n][ci] (ci contiguous), q/k/v fused into one (3H, H) matrix, ConvTranspose1d split into
+//     its `stride` output phases (n = phase*Cout + co, taps q = 0..k/stride-1 read input row u-q)
+//   * conversion to the arithmetic of the model desc (fp32 / bf16 / bf16 hi+lo)
+//   * codebook tables: centred centroids, 1/||centred||, raw centroids (I_ea/loss_fn.py:10-14)
+// The result is ONE packed device blob whose layout depends only on the model desc, so ranks that did not
+// read the checkpoint can receive it by a single RCCL broadcast (si_alloc_weights + si_weights_device_ptr).
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct HostTensor {
+    const float* data = nullptr;
+    std::vector<long> shape;
+    long numel() const { long n = 1; for (long d : shape) n *= d; return n; }
+};
+
+struct GemmW {              // one tap-GEMM weight inside the packed blob
+    size_t w = 0, w_lo = 0, bias = 0;   // byte offsets (bias: 0 = none)
+    int Cin = 0, N = 0, Npad = 0, ntaps = 0, groups = 1, math = 0;
+    bool has_bias = false;
+};
+
+struct LayerW { GemmW qkv, out, ffn1, ffn2; size_t ln1_g, ln1_b, ln2_g, ln2_b; };
+struct ConvW { GemmW g; size_t ln_g = 0, ln_b = 0; };
+struct ResW { GemmW c1[SI_MAX_DIL], c2[SI_MAX_DIL]; };
+
+struct Layout {
+    size_t total = 0;
+    // encoder
+    size_t conv0_w, conv0_bias, conv0_g, conv0_b;
+    std::vector<ConvW> convs;            // conv layers 1..n-1
+    size_t fp_ln_g, fp_ln_b; GemmW proj;
+    GemmW pos; size_t enc_ln_g, enc_ln_b;
+    std::vector<LayerW> layers;
+    size_t head_ln_g, head_ln_b; GemmW head;
+    size_t cb_centered, cb_raw, cb_rnorm;
+    // vocoder
+    GemmW pre; std::vector<GemmW> ups; std::vector<ResW> rbs;   // rbs[stage*num_rb + j]
+    size_t post_w, post_b; int post_C = 0;
+    int mel_ld = 0;                      // padded mel channel count (conv_pre Cin)
+};
+
+}  // namespace
+
+struct si_ctx {
+    int device = 0;
+    si_model_desc d{};
+    char err[512] = {0};
+    Layout lay;
+    char* wdev = nullptr;
+    bool weights_ready = false;
+    std::map<std::string, long> dbg_size;                        // floats of each intermediate of the last forward
+    std::map<std::string, std::pair<float*, long>> dbg_capture;  // name -> (device dst, capacity in floats)
+    // per-launch HIP-event timing (si_profile_start / si_profile_stop)
+    struct ProfRec { int name; hipEvent_t a, b; double flops, bytes; };
+    bool prof_on = false;
+    std::vector<std::string> prof_names;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    size_t prof_used = 0;
+    int prof_open = -1;
+};
+
+static char g_create_err[512] = "";
+
+int si_fail(si_ctx* ctx, int code, const char* fmt, ...) {
+    char* dst = ctx ? ctx->err : g_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+int si_fail_hip(si_ctx* ctx, hipError_t e, const char* what, const char* file, int line) {
+    return si_fail(ctx, SI_EHIP, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+}
+
+// Test hook: remember the size of a named intermediate and, when a capture is registered for it, copy it out
+// the moment it is produced (workspace buffers are recycled later in the same forward).
+static int si_tap(si_ctx* ctx, const char* name, const float* src, long n, hipStream_t st) {
+    ctx->dbg_size[name] = n;
+    auto it = ctx->dbg_capture.find(name);
+    if (it == ctx->dbg_capture.end()) return SI_OK;
+    const long m = n < it->second.second ? n : it->second.second;
+    if (m > 0) SI_HIP_CHECK(hipMemcpyAsync(it->second.first, src, (size_t)m * 4, hipMemcpyDeviceToDevice, st));
+    return SI_OK;
+}
+
+// Per-launch timing with HIP events recorded on the launch stream (the same stream the kernel runs on).
+// Called by every si_launch_* around its kernel; a no-op unless si_profile_start armed it.
+void si_prof_begin(si_ctx* ctx, const char* name, double flops, double bytes, hipStream_t st) {
+    if (!ctx->prof_on || ctx->prof_used + 2 > ctx->prof_pool.size()) { ctx->prof_open = -1; return; }
+    int id = -1;
+    for (size_t i = 0; i < ctx->prof_names.size(); ++i) if (ctx->prof_names[i] == name) { id = (int)i; break; }
+    if (id < 0) { id = (int)ctx->prof_names.size(); ctx->prof_names.push_back(name); }
+    si_ctx::ProfRec r{id, ctx->prof_pool[ctx->prof_used], ctx->prof_pool[ctx->prof_used + 1], flops, bytes};
+    ctx->prof_used += 2;
+    (void)hipEventRecord(r.a, st);
+    ctx->prof_open = (int)ctx->prof_recs.size();
+    ctx->prof_recs.push_back(r);
+}
+void si_prof_end(si_ctx* ctx, hipStream_t st) {
+    if (ctx->prof_open < 0) return;
+    (void)hipEventRecord(ctx->prof_recs[ctx->prof_open].b, st);
+    ctx->prof_open = -1;
+}
+
+// ------------------------------------------------------------------------------------------------ layout
+namespace {
+
+size_t elem_bytes(int math) { return math == SI_MATH_F32 ? 4 : 2; }
+
+struct Planner {
+    size_t cur = 0;
+    size_t take(size_t bytes) { size_t o = cur; cur += (bytes + 255) / 256 * 256; return o; }
+    size_t floats(size_t n) { return take(n * 4); }
+    GemmW gemm(int math, int groups, int ntaps, int N, int Cin, bool bias) {
+        GemmW g;
+        g.math = math; g.groups = groups; g.ntaps = ntaps; g.N = N; g.Cin = Cin; g.has_bias = bias;
+        g.Npad = si_round_up(N, si_pick_bn(N));
+        const size_t n = (size_t)groups * ntaps * g.Npad * Cin;
+        g.w = take(n * elem_bytes(math));
+        if (math == SI_MATH_BF16X3) g.w_lo = take(n * 2);
+        if (bias) g.bias = floats((size_t)groups * N);
+        return g;
+    }
+};
+
+int plan_layout(si_ctx* ctx) {
+    const si_model_desc& d = ctx->d;
+    Layout& L = ctx->lay;
+    Planner P;
+    P.take(256);                                           // offset 0 is reserved to mean "absent"
+    const int em = d.encoder_math, vm = d.vocoder_math;
+    const int H = d.hidden_size;
+    // encoder
+    L.conv0_w = P.floats((size_t)d.conv_dim[0] * d.conv_kernel[0]);
+    L.conv0_bias = d.conv_bias ? P.floats(d.conv_dim[0]) : 0;
+    L.conv0_g = P.floats(d.conv_dim[0]);
+    L.conv0_b = P.floats(d.conv_dim[0]);
+    L.convs.clear();
+    for (int i = 1; i < d.num_conv; ++i) {
+        ConvW c;
+        c.g = P.gemm(em, 1, d.conv_kernel[i], d.conv_dim[i], d.conv_dim[i - 1], d.conv_bias != 0);
+        if (d.feat_norm_layer) { c.ln_g = P.floats(d.conv_dim[i]); c.ln_b = P.floats(d.conv_dim[i]); }
+        L.convs.push_back(c);
+    }
+    const int CF = d.conv_dim[d.num_conv - 1];
+    L.fp_ln_g = P.floats(CF); L.fp_ln_b = P.floats(CF);
+    L.proj = P.gemm(em, 1, 1, H, CF, true);
+    L.pos = P.gemm(em, d.pos_conv_groups, d.pos_conv_kernel, H / d.pos_conv_groups, H / d.pos_conv_groups, true);
+    L.enc_ln_g = P.floats(H); L.enc_ln_b = P.floats(H);
+    L.layers.clear();
+    for (int l = 0; l < d.num_layers; ++l) {
+        LayerW w;
+        w.qkv = P.gemm(em, 1, 1, 3 * H, H, true);
+        w.out = P.gemm(em, 1, 1, H, H, true);
+        w.ln1_g = P.floats(H); w.ln1_b = P.floats(H);
+        w.ffn1 = P.gemm(em, 1, 1, d.intermediate_size, H, true);
+        w.ffn2 = P.gemm(em, 1, 1, H, d.intermediate_size, true);
+        w.ln2_g = P.floats(H); w.ln2_b = P.floats(H);
+        L.layers.push_back(w);
+    }
+    L.head_ln_g = P.floats(H); L.head_ln_b = P.floats(H);
+    L.head = P.gemm(SI_MATH_F32, 1, 1, d.codebook_dim, H, true);       // the arg-max input stays fp32
+    L.cb_centered = P.floats((size_t)d.num_clusters * d.codebook_dim);
+    L.cb_raw = P.floats((size_t)d.num_clusters * d.codebook_dim);
+    L.cb_rnorm = P.floats(d.num_clusters);
+    // vocoder
+    L.mel_ld = si_round_up(d.num_mels, 32);
+    const int C0 = d.up_initial_channel;
+    L.pre = P.gemm(vm, 1, 7, C0, L.mel_ld, true);
+    L.ups.clear(); L.rbs.clear();
+    int c = C0;
+    for (int i = 0; i < d.num_ups; ++i) {
+        const int u = d.up_rates[i], k = d.up_kernels[i];
+        L.ups.push_back(P.gemm(vm, 1, k / u, u * (c / 2), c, true));
+        c /= 2;
+        for (int j = 0; j < d.num_rb; ++j) {
+            ResW r;
+            for (int n = 0; n < d.num_dil; ++n) {
+                r.c1[n] = P.gemm(vm, 1, d.rb_kernels[j], c, c, true);
+                r.c2[n] = P.gemm(vm, 1, d.rb_kernels[j], c, c, true);
+            }
+            L.rbs.push_back(r);
+        }
+    }
+    L.post_C = c;
+    L.post_w = P.floats((size_t)7 * c);
+    L.post_b = P.floats(1);
+    L.total = P.cur;
+    return SI_OK;
+}
+
+int check_desc(si_ctx* ctx, const si_model_desc* d) {
+    if (!d || d->struct_size != (int32_t)sizeof(si_model_desc))
+        return si_fail(ctx, SI_EINVAL, "si_model_desc size mismatch (got %d, library expects %zu)", d ? d->struct_size : -1,
+                       sizeof(si_model_desc));
+    if (d->num_conv < 2 || d->num_conv > SI_MAX_CONV) return si_fail(ctx, SI_EINVAL, "num_conv=%d out of range", d->num_conv);
+    if (d->num_ups < 1 || d->num_ups > SI_MAX_UPS) return si_fail(ctx, SI_EINVAL, "num_ups=%d out of range", d->num_ups);
+    if (d->num_rb < 1 || d->num_rb > SI_MAX_RB || d->num_dil < 1 || d->num_dil > SI_MAX_DIL)
+        return si_fail(ctx, SI_EINVAL, "resblock shape %dx%d out of range", d->num_rb, d->num_dil);
+    if (d->hidden_size <= 0 || d->num_heads <= 0 || d->hidden_size != d->num_heads * 64)
+        return si_fail(ctx, SI_EINVAL, "hidden_size=%d / heads=%d: the attention kernel needs head_dim 64", d->hidden_size, d->num_heads);
+    if (d->pos_conv_groups <= 0 || d->hidden_size % d->pos_conv_groups || (d->hidden_size / d->pos_conv_groups) % 16)
+        return si_fail(ctx, SI_EINVAL, "positional conv: hidden/groups must be a multiple of 16");
+    for (int i = 0; i < d->num_conv; ++i)
+        if (d->conv_dim[i] % 16 || d->conv_kernel[i] <= 0 || d->conv_stride[i] <= 0)
+            return si_fail(ctx, SI_EINVAL, "conv layer %d: dim %d must be a multiple of 16", i, d->conv_dim[i]);
+    if (d->hidden_size % 16 || d->intermediate_size % 16) return si_fail(ctx, SI_EINVAL, "hidden / intermediate sizes must be multiples of 16");
+    if (d->codebook_dim <= 0 || d->codebook_dim > 128 || d->num_clusters <= 0) return si_fail(ctx, SI_EINVAL, "codebook %dx%d unsupported", d->num_clusters, d->codebook_dim);
+    if (d->codebook_dim != d->num_mels) return si_fail(ctx, SI_EINVAL, "codebook_dim %d != num_mels %d: centroids are mel frames", d->codebook_dim, d->num_mels);
+    int c = d->up_initial_channel;
+    for (int i = 0; i < d->num_ups; ++i) {
+        if (d->up_kernels[i] % d->up_rates[i] || (d->up_kernels[i] - d->up_rates[i]) % 2)
+            return si_fail(ctx, SI_EINVAL, "upsample %d: kernel %d must be a multiple of rate %d with even difference", i, d->up_kernels[i], d->up_rates[i]);
+        if (c % 32) return si_fail(ctx, SI_EINVAL, "upsample %d: %d input channels must be a multiple of 32", i, c);
+        c /= 2;
+    }
+    if (c % 4) return si_fail(ctx, SI_EINVAL, "final generator width %d must be a multiple of 4", c);
+    for (int j = 0; j < d->num_rb; ++j)
+        if (d->rb_kernels[j] % 2 == 0) return si_fail(ctx, SI_EINVAL, "resblock kernel %d must be odd", d->rb_kernels[j]);
+    for (int m : {d->encoder_math, d->vocoder_math})
+        if (m < SI_MATH_F32 || m > SI_MATH_BF16X3) return si_fail(ctx, SI_EINVAL, "unknown math mode %d", m);
+    return SI_OK;
+}
+
+// ---- host packing helpers ------------------------------------------------------------------------
+unsigned short h_f2bf(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+float h_bf2f(unsigned short h) { unsigned u = ((unsigned)h) << 16; float f; memcpy(&f, &u, 4); return f; }
+
+struct Packer {
+    si_ctx* ctx;
+    std::map<std::string, HostTensor> t;
+    std::vector<char> out;
+    int rc = SI_OK;
+
+    const HostTensor* get(const std::string& name, std::initializer_list<long> shape) {
+        auto it = t.find(name);
+        if (it == t.end()) { if (!rc) rc = si_fail(ctx, SI_EWEIGHTS, "checkpoint is missing tensor '%s'", name.c_str()); return nullptr; }
+        std::vector<long> want(shape);
+        if (it->second.shape != want) {
+            std::ostringstream a, b;
+            for (long v : it->second.shape) a << v << ' ';
+            for (long v : want) b << v << ' ';
+            if (!rc) rc = si_fail(ctx, SI_EWEIGHTS, "tensor '%s' has shape [%s] but the model needs [%s]", name.c_str(), a.str().c_str(), b.str().c_str());
+            return nullptr;
+        }
+        return &it->second;
+    }
+    bool has(const std::string& n) const { return t.count(n) != 0; }
+    float* fptr(size_t off) { return reinterpret_cast<float*>(out.data() + off); }
+    void copy_floats(size_t off, const std::string& name, long n) {
+        const HostTensor* h = get(name, {n});
+        if (h) memcpy(out.data() + off, h->data, (size_t)n * 4);
+    }
+    // Folded weight of a conv-like module (shape `shape`); norm_dim = the dim weight_norm keeps.
+    bool folded(const std::string& prefix, std::initializer_list<long> shape, int norm_dim, std::vector<float>& w) {
+        std::vector<long> sh(shape);
+        long n = 1; for (long v : sh) n *= v;
+        if (has(prefix + ".weight")) {
+            const HostTensor* h = get(prefix + ".weight", shape);
+            if (!h) return false;
+            w.assign(h->data, h->data + n);
+            return true;
+        }
+        std::string gn = prefix + ".weight_g", vn = prefix + ".weight_v";
+        if (!has(gn)) { gn = prefix + ".parametrizations.weight.original0"; vn = prefix + ".parametrizations.weight.original1"; }
+        if (!has(gn)) { if (!rc) rc = si_fail(ctx, SI_EWEIGHTS, "checkpoint has neither '%s.weight' nor a weight-norm pair", prefix.c_str()); return false; }
+        const HostTensor* v = get(vn, shape);
+        if (!v) return false;
+        auto git = t.find(gn);
+        const long keep = sh[norm_dim];
+        if (git->second.numel() != keep) { if (!rc) rc = si_fail(ctx, SI_EWEIGHTS, "'%s' must hold %ld magnitudes", gn.c_str(), keep); return false; }
+        long inner = 1; for (size_t i = norm_dim + 1; i < sh.size(); ++i) inner *= sh[i];
+        std::vector<double> ss(keep, 0.0);
+        for (long i = 0; i < n; ++i) { const long kidx = (i / inner) % keep; ss[kidx] += (double)v->data[i] * v->data[i]; }
+        w.resize(n);
+        for (long i = 0; i < n; ++i) {
+            const long kidx = (i / inner) % keep;
+            // same operation order as torch._weight_norm: v * (g / norm), all in fp32
+            const float nrm = (float)std::sqrt(ss[kidx]);
+            w[i] = v->data[i] * (git->second.data[kidx] / nrm);
+        }
+        return true;
+    }
+    // store element (g, tap, n, ci) of a tap-GEMM weight
+    void put(const GemmW& G, int g, int tap, int n, int ci, float v) {
+        const size_t idx = (((size_t)g * G.ntaps + tap) * G.Npad + n) * G.Cin + ci;
+        if (G.math == SI_MATH_F32) { fptr(G.w)[idx] = v; return; }
+        const unsigned short hi = h_f2bf(v);
+        reinterpret_cast<unsigned short*>(out.data() + G.w)[idx] = hi;
+        if (G.math == SI_MATH_BF16X3) reinterpret_cast<unsigned short*>(out.data() + G.w_lo)[idx] = h_f2bf(v - h_bf2f(hi));
+    }
+    // Conv1d weight (Cout, Cin/groups, k) -> W[g][tap][n][ci]; cin_valid < G.Cin leaves zero padding
+    void conv(const GemmW& G, const std::vector<float>& w, int cout_total, int cin_g, int k) {
+        const int npg = cout_total / G.groups;
+        for (int co = 0; co < cout_total; ++co)
+            for (int ci = 0; ci < cin_g; ++ci)
+                for (int tp = 0; tp < k; ++tp)
+                    put(G, co / npg, tp, co % npg, ci, w[((size_t)co * cin_g + ci) * k + tp]);
+    }
+    void bias(const GemmW& G, const std::string& name, long n) { if (G.has_bias) copy_floats(G.bias, name, n); }
+};
+
+int parse_index(si_ctx* ctx, const char* index, const void* blob, size_t nbytes, std::map<std::string, HostTensor>& out) {
+    std::istringstream in(index ? index : "");
+    std::string line;
+    int lineno = 0;
+    while (std::getline(in, line)) {
+        ++lineno;
+        if (line.empty()) continue;
+        std::istringstream ls(line);
+        std::string name; long long off; int nd;
+        if (!(ls >> name >> off >> nd) || nd < 0 || nd > 8) return si_fail(ctx, SI_EWEIGHTS, "index line %d is malformed: '%s'", lineno, line.c_str());
+        HostTensor t;
+        for (int i = 0; i < nd; ++i) { long v; if (!(ls >> v) || v < 0) return si_fail(ctx, SI_EWEIGHTS, "index line %d: bad dims", lineno); t.shape.push_back(v); }
+        if (off < 0 || off % 4 || (size_t)off + (size_t)t.numel() * 4 > nbytes)
+            return si_fail(ctx, SI_EWEIGHTS, "tensor '%s' (offset %lld, %ld floats) does not fit the %zu-byte blob", name.c_str(), off, t.numel(), nbytes);
+        t.data = reinterpret_cast<const float*>(static_cast<const char*>(blob) + off);
+        out[name] = t;
+    }
+    if (out.empty()) return si_fail(ctx, SI_EWEIGHTS, "checkpoint index is empty");
+    return SI_OK;
+}
+
+int pack_weights(si_ctx* ctx, Packer& P) {
+    const si_model_desc& d = ctx->d;
+    const Layout& L = ctx->lay;
+    P.out.assign(L.total, 0);
+    const std::string B = "base_model.";
+    const int H = d.hidden_size;
+    std::vector<float> w;
+    // ---- feature extractor
+    {
+        const std::string p0 = B + "feature_extractor.conv_layers.0.";
+        const HostTensor* h = P.get(p0 + "conv.weight", {d.conv_dim[0], 1, d.conv_kernel[0]});
+        if (h) memcpy(P.out.data() + L.conv0_w, h->data, (size_t)h->numel() * 4);
+        if (d.conv_bias) P.copy_floats(L.conv0_bias, p0 + "conv.bias", d.conv_dim[0]);
+        P.copy_floats(L.conv0_g, p0 + "layer_norm.weight", d.conv_dim[0]);
+        P.copy_floats(L.conv0_b, p0 + "layer_norm.bias", d.conv_dim[0]);
+    }
+    for (int i = 1; i < d.num_conv; ++i) {
+        const std::string p = B + "feature_extractor.conv_layers." + std::to_string(i) + ".";
+        const ConvW& c = L.convs[i - 1];
+        const HostTensor* h = P.get(p + "conv.weight", {d.conv_dim[i], d.conv_dim[i - 1], d.conv_kernel[i]});
+        if (h) { w.assign(h->data, h->data + h->numel()); P.conv(c.g, w, d.conv_dim[i], d.conv_dim[i - 1], d.conv_kernel[i]); }
+        P.bias(c.g, p + "conv.bias", d.conv_dim[i]);
+        if (d.feat_norm_layer) { P.copy_floats(c.ln_g, p + "layer_norm.weight", d.conv_dim[i]); P.copy_floats(c.ln_b, p + "layer_norm.bias", d.conv_dim[i]); }
+    }
+    const int CF = d.conv_dim[d.num_conv - 1];
+    if (d.feat_proj_layer_norm) {
+        P.copy_floats(L.fp_ln_g, B + "feature_projection.layer_norm.weight", CF);
+        P.copy_floats(L.fp_ln_b, B + "feature_projection.layer_norm.bias", CF);
+    }
+    auto linear = [&](const GemmW& G, const std::string& name, int nout, int nin, int row0 = 0) {
+        const HostTensor* h = P.get(name + ".weight", {nout, nin});
+        if (h) for (int o = 0; o < nout; ++o) for (int i = 0; i < nin; ++i) P.put(G, 0, 0, row0 + o, i, h->data[(size_t)o * nin + i]);
+        const HostTensor* b = P.get(name + ".bias", {nout});
+        if (b) memcpy(P.fptr(G.bias) + row0, b->data, (size_t)nout * 4);
+    };
+    linear(L.proj, B + "feature_projection.projection", H, CF);
+    {
+        const int cg = H / d.pos_conv_groups;
+        if (P.folded(B + "encoder.pos_conv_embed.conv", {H, cg, d.pos_conv_kernel}, 2, w)) P.conv(L.pos, w, H, cg, d.pos_conv_kernel);
+        P.bias(L.pos, B + "encoder.pos_conv_embed.conv.bias", H);
+    }
+    P.copy_floats(L.enc_ln_g, B + "encoder.layer_norm.weight", H);
+    P.copy_floats(L.enc_ln_b, B + "encoder.layer_norm.bias", H);
+    for (int l = 0; l < d.num_layers; ++l) {
+        const std::string p = B + "encoder.layers." + std::to_string(l) + ".";
+        const LayerW& W = L.layers[l];
+        linear(W.qkv, p + "attention.q_proj", H, H, 0);
+        linear(W.qkv, p + "attention.k_proj", H, H, H);
+        linear(W.qkv, p + "attention.v_proj", H, H, 2 * H);
+        linear(W.out, p + "attention.out_proj", H, H);
+        P.copy_floats(W.ln1_g, p + "layer_norm.weight", H); P.copy_floats(W.ln1_b, p + "layer_norm.bias", H);
+        linear(W.ffn1, p + "feed_forward.intermediate_dense", d.intermediate_size, H);
+        linear(W.ffn2, p + "feed_forward.output_dense", H, d.intermediate_size);
+        P.copy_floats(W.ln2_g, p + "final_layer_norm.weight", H); P.copy_floats(W.ln2_b, p + "final_layer_norm.bias", H);
+    }
+    P.copy_floats(L.head_ln_g, "final_layers.0.weight", H);
+    P.copy_floats(L.head_ln_b, "final_layers.0.bias", H);
+    linear(L.head, "final_layers.1", d.codebook_dim, H);
+    // ---- codebook tables (I_ea/loss_fn.py:10-14): centre = mean over K; centred; 1/max(||centred||, 1e-8)
+    {
+        const int K = d.num_clusters, D = d.codebook_dim;
+        const HostTensor* c = P.get("codebook", {K, D});
+        if (c) {
+            std::vector<float> center(D, 0.f);
+            for (int j = 0; j < D; ++j) { float s = 0.f; for (int k = 0; k < K; ++k) s += c->data[(size_t)k * D + j]; center[j] = s / K; }
+            float* cc = P.fptr(L.cb_centered); float* raw = P.fptr(L.cb_raw); float* rn = P.fptr(L.cb_rnorm);
+            for (int k = 0; k < K; ++k) {
+                double ss = 0;
+                for (int j = 0; j < D; ++j) {
+                    const float v = c->data[(size_t)k * D + j] - center[j];
+                    cc[(size_t)k * D + j] = v;
+                    raw[(size_t)k * D + j] = v + center[j];        // predict.py:184: all_embeds_t_c + center_
+                    ss += (double)v * v;
+                }
+                rn[k] = 1.0f / fmaxf((float)std::sqrt(ss), 1e-8f);
+            }
+        }
+    }
+    // ---- generator
+    const std::string G = "generator.";
+    const int C0 = d.up_initial_channel;
+    if (P.folded(G + "conv_pre", {C0, d.num_mels, 7}, 0, w)) P.conv(L.pre, w, C0, d.num_mels, 7);
+    P.bias(L.pre, G + "conv_pre.bias", C0);
+    int c = C0;
+    for (int i = 0; i < d.num_ups; ++i) {
+        const int u = d.up_rates[i], k = d.up_kernels[i], cout = c / 2;
+        const GemmW& U = L.ups[i];
+        // ConvTranspose1d weight (Cin, Cout, k), weight-norm over dim 0 (= Cin).  Phase p = j mod u, tap q = j / u.
+        if (P.folded(G + "ups." + std::to_string(i), {c, cout, k}, 0, w))
+            for (int ci = 0; ci < c; ++ci)
+                for (int co = 0; co < cout; ++co)
+                    for (int j = 0; j < k; ++j) P.put(U, 0, j / u, (j % u) * cout + co, ci, w[((size_t)ci * cout + co) * k + j]);
+        const HostTensor* b = P.get(G + "ups." + std::to_string(i) + ".bias", {cout});
+        if (b) for (int ph = 0; ph < u; ++ph) memcpy(P.fptr(U.bias) + (size_t)ph * cout, b->data, (size_t)cout * 4);
+        c = cout;
+        for (int j = 0; j < d.num_rb; ++j) {
+            const ResW& R = L.rbs[(size_t)i * d.num_rb + j];
+            const std::string rp = G + "resblocks." + std::to_string(i * d.num_rb + j) + ".";
+            for (int n = 0; n < d.num_dil; ++n) {
+                const std::string a = rp + "convs1." + std::to_string(n), bb = rp + "convs2." + std::to_string(n);
+                if (P.folded(a, {c, c, d.rb_kernels[j]}, 0, w)) P.conv(R.c1[n], w, c, c, d.rb_kernels[j]);
+                P.bias(R.c1[n], a + ".bias", c);
+                if (P.folded(bb, {c, c, d.rb_kernels[j]}, 0, w)) P.conv(R.c2[n], w, c, c, d.rb_kernels[j]);
+                P.bias(R.c2[n], bb + ".bias", c);
+            }
+        }
+    }
+    if (P.folded(G + "conv_post", {1, c, 7}, 0, w))
+        for (int ci = 0; ci < c; ++ci) for (int k = 0; k < 7; ++k) P.fptr(L.post_w)[(size_t)k * c + ci] = w[(size_t)ci * 7 + k];
+    P.copy_floats(L.post_b, G + "conv_post.bias", 1);
+    return P.rc;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {
+    char* base; size_t cap; size_t cur = 0; bool ok = true;
+    float* floats(size_t n) { return reinterpret_cast<float*>(bytes(n * 4)); }
+    char* bytes(size_t n) {
+        size_t o = cur; cur = align_up(cur + n, 256);
+        if (cur > cap) { ok = false; return base; }
+        return base + o;
+    }
+};
+
+struct EncDims { int T; std::vector<int> L; };
+EncDims enc_dims(const si_model_desc& d, int N) {
+    EncDims e; e.L.push_back(N);
+    int n = N;
+    for (int i = 0; i < d.num_conv; ++i) { n = n >= d.conv_kernel[i] ? (n - d.conv_kernel[i]) / d.conv_stride[i] + 1 : 0; e.L.push_back(n); }
+    e.T = n;
+    return e;
+}
+
+size_t encoder_ws_bytes(const si_model_desc& d, int B, int N) {
+    EncDims e = enc_dims(d, N);
+    size_t cmax = 0;
+    for (int i = 0; i < d.num_conv; ++i) cmax = std::max(cmax, (size_t)e.L[i + 1] * d.conv_dim[i]);
+    const size_t BT = (size_t)B * std::max(e.T, 1);
+    size_t f = 2 * (size_t)B * cmax + BT * d.conv_dim[d.num_conv - 1] + BT * d.hidden_size * 3 + BT * 3 * d.hidden_size + BT * d.intermediate_size +
+               (size_t)B * d.conv_dim[0] * 2;
+    return f * 4 + (size_t)B * 16 + si_conv0_partials_bytes(B, N) + 32 * 256;
+}
+
+int vocoder_chunk(const si_model_desc& d, int B) { int c = d.vocoder_chunk > 0 ? d.vocoder_chunk : 4; return std::min(c, std::max(B, 1)); }
+
+long voc_tout(int Tm, int stretch) { return stretch ? (long)std::floor((double)Tm * (441.0 / 256.0)) : Tm; }
+
+size_t vocoder_ws_bytes(const si_ctx* ctx, int B, int Tm, int stretch) {
+    const si_model_desc& d = ctx->d;
+    const int Bc = vocoder_chunk(d, B);
+    const long Tout = voc_tout(Tm, stretch);
+    size_t lc_max = (size_t)Tout * d.up_initial_channel;
+    long L = Tout; int c = d.up_initial_channel;
+    for (int i = 0; i < d.num_ups; ++i) { L *= d.up_rates[i]; c /= 2; lc_max = std::max(lc_max, (size_t)L * c); }
+    size_t f = (size_t)Bc * Tout * ctx->lay.mel_ld + 6 * (size_t)Bc * lc_max;
+    return f * 4 + 16 * 256;
+}
+
+TapGemmParams gemm_params(const si_ctx* ctx, const GemmW& G) {
+    TapGemmParams p{};
+    p.w = ctx->wdev + G.w;
+    p.w_lo = G.math == SI_MATH_BF16X3 ? ctx->wdev + G.w_lo : nullptr;
+    p.bias = G.has_bias ? reinterpret_cast<const float*>(ctx->wdev + G.bias) : nullptr;
+    p.Cin = G.Cin; p.N = G.N; p.Npad = G.Npad; p.ntaps = G.ntaps; p.groups = G.groups;
+    p.stride = 1; p.dil = 1; p.pad = 0; p.pro_slope = 1.f; p.act = SI_ACT_NONE; p.alpha = 1.f; p.accumulate = 0;
+    p.nseg = 1;
+    return p;
+}
+
+// y(rows x N) = x(rows x K) W^T + b [+act] [+res]
+int linear(si_ctx* ctx, const GemmW& G, const float* x, float* y, long rows, int act, const float* res, hipStream_t st) {
+    TapGemmParams p = gemm_params(ctx, G);
+    p.x = x; p.out = y; p.res = res; p.act = act;
+    p.nseg = 1; p.Lin = (int)rows; p.M = (int)rows; p.ldx = G.Cin; p.x_seg_stride = 0;
+    p.ldo = G.N; p.o_seg_stride = 0; p.ooff = 0; p.olimit = rows * G.N;
+    return si_launch_tapgemm(ctx, G.math, p, st);
+}
+
+const float* wf(const si_ctx* ctx, size_t off) { return reinterpret_cast<const float*>(ctx->wdev + off); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int si_version(void) { return SI_ABI_VERSION; }
+
+const char* si_last_error(const si_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
+
+int si_create(si_ctx** out, int device_id, const si_model_desc* desc) {
+    if (!out) return si_fail(nullptr, SI_EINVAL, "si_create: out is NULL");
+    *out = nullptr;
+    int rc = check_desc(nullptr, desc);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev)
+        return si_fail(nullptr, SI_EHIP, "si_create: device %d not available (%d HIP devices visible)", device_id, ndev);
+    si_ctx* ctx = new si_ctx();
+    ctx->device = device_id;
+    ctx->d = *desc;
+    plan_layout(ctx);
+    *out = ctx;
+    return SI_OK;
+}
+
+void si_destroy(si_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->wdev) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->wdev); }
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+int si_alloc_weights(si_ctx* ctx) {
+    if (!ctx) return SI_EINVAL;
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->wdev) SI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->wdev), ctx->lay.total));
+    ctx->weights_ready = true;          // bytes arrive by broadcast before the first forward
+    return SI_OK;
+}
+
+int si_load_weights(si_ctx* ctx, const void* host_blob, size_t nbytes, const char* index) {
+    if (!ctx || !host_blob || !index) return si_fail(ctx, SI_EINVAL, "si_load_weights: NULL argument");
+    Packer P;
+    P.ctx = ctx;
+    int rc = parse_index(ctx, index, host_blob, nbytes, P.t);
+    if (rc) return rc;
+    rc = pack_weights(ctx, P);
+    if (rc) return rc;
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->wdev) SI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->wdev), ctx->lay.total));
+    SI_HIP_CHECK(hipMemcpy(ctx->wdev, P.out.data(), ctx->lay.total, hipMemcpyHostToDevice));
+    ctx->weights_ready = true;
+    return SI_OK;
+}
+
+int si_weights_device_ptr(si_ctx* ctx, void** ptr, size_t* nbytes) {
+    if (!ctx || !ptr || !nbytes) return si_fail(ctx, SI_EINVAL, "si_weights_device_ptr: NULL argument");
+    if (!ctx->wdev) return si_fail(ctx, SI_ESTATE, "weights are not allocated: call si_load_weights or si_alloc_weights first");
+    *ptr = ctx->wdev;
+    *nbytes = ctx->lay.total;
+    return SI_OK;
+}
+
+int si_num_frames(const si_ctx* ctx, int N) { return ctx ? enc_dims(ctx->d, N).T : SI_EINVAL; }
+
+int si_vocoder_samples(const si_ctx* ctx, int Tm, int stretch) {
+    if (!ctx) return SI_EINVAL;
+    long L = voc_tout(Tm, stretch);
+    for (int i = 0; i < ctx->d.num_ups; ++i) L *= ctx->d.up_rates[i];
+    return (int)L;
+}
+
+int si_workspace_bytes(si_ctx* ctx, int B, int N, int Tm, size_t* out) {
+    if (!ctx || !out || B <= 0) return si_fail(ctx, SI_EINVAL, "si_workspace_bytes: bad argument");
+    size_t a = N > 0 ? encoder_ws_bytes(ctx->d, B, N) : 0;
+    size_t b = Tm > 0 ? vocoder_ws_bytes(ctx, B, Tm, 1) : 0;
+    *out = std::max(a, b);
+    return SI_OK;
+}
+
+int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len, int normalize, int B, int N,
+                      float* out_feats, void* workspace, size_t workspace_bytes, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!ctx->weights_ready) return si_fail(ctx, SI_ESTATE, "si_hubert_forward before weights were loaded");
+    if (!wav || !out_feats || !workspace || B <= 0) return si_fail(ctx, SI_EINVAL, "si_hubert_forward: NULL / empty argument");
+    const si_model_desc& d = ctx->d;
+    const Layout& L = ctx->lay;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const EncDims e = enc_dims(d, N);
+    if (e.T < 1) return si_fail(ctx, SI_EINVAL, "clip of %d samples is shorter than the conv stack's receptive field", N);
+    if (workspace_bytes < encoder_ws_bytes(d, B, N))
+        return si_fail(ctx, SI_ENOMEM, "workspace of %zu bytes < %zu needed for B=%d N=%d", workspace_bytes, encoder_ws_bytes(d, B, N), B, N);
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    const int T = e.T, H = d.hidden_size, I = d.intermediate_size, CF = d.conv_dim[d.num_conv - 1];
+    const long BT = (long)B * T;
+    size_t cmax = 0;
+    for (int i = 0; i < d.num_conv; ++i) cmax = std::max(cmax, (size_t)e.L[i + 1] * d.conv_dim[i]);
+
+    Carver W{static_cast<char*>(workspace), workspace_bytes};
+    double* stats = reinterpret_cast<double*>(W.bytes((size_t)B * 16));
+    double* partials = reinterpret_cast<double*>(W.bytes(si_conv0_partials_bytes(B, N)));
+    float* affine = W.floats((size_t)B * d.conv_dim[0] * 2);
+    float* cbuf[2] = {W.floats((size_t)B * cmax), W.floats((size_t)B * cmax)};
+    float* lnf = W.floats(BT * CF);
+    float* h = W.floats(BT * H);
+    float* h2 = W.floats(BT * H);
+    float* att = W.floats(BT * H);
+    float* qkv = W.floats(BT * 3 * H);
+    float* ffn = W.floats(BT * I);
+    if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: encoder workspace carve exceeded its own estimate");
+    ctx->dbg_size.clear();
+
+    int rc;
+    // A0 + A1: normalise fused into conv0
+    WaveNormParams wp{wav, mask_start, mask_len, B, N, e.L[1], d.conv_dim[0], d.conv_kernel[0], d.conv_stride[0], normalize};
+    if ((rc = si_launch_wave_stats(ctx, wp, stats, st))) return rc;
+    if (!d.feat_norm_layer) {
+        rc = si_launch_conv0_groupnorm(ctx, wp, stats, wf(ctx, L.conv0_w), wf(ctx, L.conv0_g), wf(ctx, L.conv0_b), partials, affine, cbuf[0], st);
+    } else {
+        rc = si_launch_conv0_affine(ctx, wp, stats, wf(ctx, L.conv0_w), d.conv_bias ? wf(ctx, L.conv0_bias) : nullptr, affine, cbuf[0], st);
+        if (!rc) rc = si_launch_layernorm(ctx, cbuf[0], nullptr, wf(ctx, L.conv0_g), wf(ctx, L.conv0_b), cbuf[0], (long)B * e.L[1], d.conv_dim[0], 1e-5f, 1, st);
+    }
+    if (rc) return rc;
+    // A2: strided convs as tap-GEMMs
+    int cur = 0;
+    for (int i = 1; i < d.num_conv; ++i) {
+        const ConvW& c = L.convs[i - 1];
+        TapGemmParams p = gemm_params(ctx, c.g);
+        p.x = cbuf[cur]; p.out = cbuf[cur ^ 1];
+        p.nseg = B; p.Lin = e.L[i]; p.M = e.L[i + 1]; p.ldx = d.conv_dim[i - 1]; p.x_seg_stride = (long)e.L[i] * d.conv_dim[i - 1];
+        p.stride = d.conv_stride[i]; p.ldo = d.conv_dim[i]; p.o_seg_stride = (long)e.L[i + 1] * d.conv_dim[i];
+        p.olimit = p.o_seg_stride;
+        p.act = d.feat_norm_layer ? SI_ACT_NONE : SI_ACT_GELU;
+        if ((rc = si_launch_tapgemm(ctx, c.g.math, p, st))) return rc;
+        cur ^= 1;
+        if (d.feat_norm_layer &&
+            (rc = si_launch_layernorm(ctx, cbuf[cur], nullptr, wf(ctx, c.ln_g), wf(ctx, c.ln_b), cbuf[cur], (long)B * e.L[i + 1], d.conv_dim[i], 1e-5f, 1, st)))
+            return rc;
+    }
+    const float* feat = cbuf[cur];                                   // (B, T, CF)
+    if ((rc = si_tap(ctx, "features", feat, BT * CF, st))) return rc;
+    // A3: LN + projection
+    const float* pin = feat;
+    if (d.feat_proj_layer_norm) {
+        if ((rc = si_launch_layernorm(ctx, feat, nullptr, wf(ctx, L.fp_ln_g), wf(ctx, L.fp_ln_b), lnf, BT, CF, d.layer_norm_eps, 0, st))) return rc;
+        pin = lnf;
+    }
+    if ((rc = linear(ctx, L.proj, pin, h, BT, SI_ACT_NONE, nullptr, st))) return rc;
+    if ((rc = si_tap(ctx, "projected", h, BT * H, st))) return rc;
+    // A4: h2 = h + gelu(pos_conv(h) + b)
+    {
+        TapGemmParams p = gemm_params(ctx, L.pos);
+        p.x = h; p.out = h2; p.res = h;
+        p.nseg = B; p.Lin = T; p.M = T; p.ldx = H; p.x_seg_stride = (long)T * H;
+        p.pad = d.pos_conv_kernel / 2; p.ldo = H; p.o_seg_stride = (long)T * H; p.olimit = p.o_seg_stride;
+        p.act = SI_ACT_GELU;
+        if ((rc = si_launch_tapgemm(ctx, L.pos.math, p, st))) return rc;
+    }
+    const float eps = d.layer_norm_eps;
+    if (!d.stable_layer_norm) {
+        if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, L.enc_ln_g), wf(ctx, L.enc_ln_b), h, BT, H, eps, 0, st))) return rc;
+    } else {
+        std::swap(h, h2);
+    }
+    if ((rc = si_tap(ctx, "encoder_in", h, BT * H, st))) return rc;
+    // A5..A8
+    for (int l = 0; l < d.num_layers; ++l) {
+        const LayerW& Wl = L.layers[l];
+        if (!d.stable_layer_norm) {       // post-LN (modeling_hubert.py:371-404)
+            if ((rc = linear(ctx, Wl.qkv, h, qkv, BT, SI_ACT_NONE, nullptr, st))) return rc;
+            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st))) return rc;
+            if ((rc = linear(ctx, Wl.out, att, h2, BT, SI_ACT_NONE, h, st))) return rc;
+            if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h, BT, H, eps, 0, st))) return rc;
+            if ((rc = linear(ctx, Wl.ffn1, h, ffn, BT, SI_ACT_GELU, nullptr, st))) return rc;
+            if ((rc = linear(ctx, Wl.ffn2, ffn, h2, BT, SI_ACT_NONE, h, st))) return rc;
+            if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h, BT, H, eps, 0, st))) return rc;
+        } else {                          // pre-LN "stable" (modeling_hubert.py:504-547); residual adds are in place
+            if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h2, BT, H, eps, 0, st))) return rc;
+            if ((rc = linear(ctx, Wl.qkv, h2, qkv, BT, SI_ACT_NONE, nullptr, st))) return rc;
+            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st))) return rc;
+            if ((rc = linear(ctx, Wl.out, att, h, BT, SI_ACT_NONE, h, st))) return rc;
+            if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h2, BT, H, eps, 0, st))) return rc;
+            if ((rc = linear(ctx, Wl.ffn1, h2, ffn, BT, SI_ACT_GELU, nullptr, st))) return rc;
+            if ((rc = linear(ctx, Wl.ffn2, ffn, h, BT, SI_ACT_NONE, h, st))) return rc;
+        }
+    }
+    if (d.stable_layer_norm) {
+        if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, L.enc_ln_g), wf(ctx, L.enc_ln_b), h2, BT, H, eps, 0, st))) return rc;
+        std::swap(h, h2);
+    }
+    if ((rc = si_tap(ctx, "last_hidden", h, BT * H, st))) return rc;
+    // A9: final_layers = LN -> Linear(H, codebook_dim), always fp32
+    if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, L.head_ln_g), wf(ctx, L.head_ln_b), h2, BT, H, 1e-5f, 0, st))) return rc;
+    return linear(ctx, L.head, h2, out_feats, BT, SI_ACT_NONE, nullptr, st);
+}
+
+int si_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, const int32_t* frame_pos, int Lm, float* mel, int Tm,
+                       int64_t* labels, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!ctx->weights_ready) return si_fail(ctx, SI_ESTATE, "si_codebook_splice before weights were loaded");
+    if (!feats || !frame_pos || !mel || B <= 0 || Lm < 0) return si_fail(ctx, SI_EINVAL, "si_codebook_splice: NULL / empty argument");
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    const Layout& L = ctx->lay;
+    return si_launch_codebook_splice(ctx, feats, B, T, ctx->d.codebook_dim, frame_pos, Lm, wf(ctx, L.cb_centered), wf(ctx, L.cb_raw),
+                                     wf(ctx, L.cb_rnorm), ctx->d.num_clusters, mel, Tm, labels, static_cast<hipStream_t>(stream));
+}
+
+int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch, float* wav_out, void* workspace,
+                       size_t workspace_bytes, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!ctx->weights_ready) return si_fail(ctx, SI_ESTATE, "si_hifigan_forward before weights were loaded");
+    if (!mel || !wav_out || !workspace || B <= 0 || Tm <= 0) return si_fail(ctx, SI_EINVAL, "si_hifigan_forward: NULL / empty argument");
+    const si_model_desc& d = ctx->d;
+    const Layout& Ly = ctx->lay;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t need = vocoder_ws_bytes(ctx, B, Tm, stretch);
+    if (workspace_bytes < need) return si_fail(ctx, SI_ENOMEM, "workspace of %zu bytes < %zu needed for B=%d Tm=%d", workspace_bytes, need, B, Tm);
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    const int Bc_max = vocoder_chunk(d, B);
+    const long Tout = voc_tout(Tm, stretch);
+    if (Tout < 1) return si_fail(ctx, SI_EINVAL, "mel of %d frames stretches to nothing", Tm);
+    size_t lc_max = (size_t)Tout * d.up_initial_channel;
+    {
+        long L = Tout; int c = d.up_initial_channel;
+        for (int i = 0; i < d.num_ups; ++i) { L *= d.up_rates[i]; c /= 2; lc_max = std::max(lc_max, (size_t)L * c); }
+    }
+    const long Lwav = si_vocoder_samples(ctx, Tm, stretch);
+    Carver W{static_cast<char*>(workspace), workspace_bytes};
+    float* ext = W.floats((size_t)Bc_max * Tout * Ly.mel_ld);
+    float* buf[6];
+    for (auto& b : buf) b = W.floats((size_t)Bc_max * lc_max);
+    if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: vocoder workspace carve exceeded its own estimate");
+    ctx->dbg_size.clear();
+    const int nk = d.num_rb;
+    static const char* upn[] = {"ups0", "ups1", "ups2", "ups3", "ups4", "ups5", "ups6", "ups7"};
+    static const char* stn[] = {"stage0", "stage1", "stage2", "stage3", "stage4", "stage5", "stage6", "stage7"};
+
+    for (int b0 = 0; b0 < B; b0 += Bc_max) {
+        const int Bc = std::min(Bc_max, B - b0);
+        int rc;
+        // A14: stretch + transpose to channels-last
+        if ((rc = si_launch_extend_mel(ctx, mel + (size_t)b0 * d.num_mels * Tm, Bc, d.num_mels, Tm, (int)Tout, stretch, ext, Ly.mel_ld, st))) return rc;
+        // B1: conv_pre
+        float* x = buf[0];
+        float* xs = buf[1];
+        {
+            TapGemmParams p = gemm_params(ctx, Ly.pre);
+            p.x = ext; p.out = x;
+            p.nseg = Bc; p.Lin = (int)Tout; p.M = (int)Tout; p.ldx = Ly.mel_ld; p.x_seg_stride = Tout * Ly.mel_ld;
+            p.algo_macs = (double)Bc * Tout * d.up_initial_channel * (double)d.num_mels * 7;
+            p.pad = 3; p.ldo = d.up_initial_channel; p.o_seg_stride = Tout * d.up_initial_channel; p.olimit = p.o_seg_stride;
+            if ((rc = si_launch_tapgemm(ctx, Ly.pre.math, p, st))) return rc;
+        }
+        long Lc = Tout; int c = d.up_initial_channel;
+        for (int i = 0; i < d.num_ups; ++i) {
+            const int u = d.up_rates[i], k = d.up_kernels[i], cout = c / 2, pad = (k - u) / 2;
+            const long Lo = Lc * u;
+            float* U = buf[2];
+            // B2: leaky_relu(0.1) -> ConvTranspose1d as `u` phases of a 2-tap conv: row u' reads input rows u', u'-1, ...
+            {
+                TapGemmParams p = gemm_params(ctx, Ly.ups[i]);
+                p.x = x; p.out = U;
+                p.nseg = Bc; p.Lin = (int)Lc; p.M = (int)((pad + Lo - 1) / u + 1); p.ldx = c; p.x_seg_stride = Lc * c;
+                p.dil = -1; p.ldo = u * cout; p.o_seg_stride = Lo * cout; p.ooff = -(long)pad * cout; p.olimit = Lo * cout;
+                p.pro_slope = 0.1f;
+                p.algo_macs = (double)Bc * Lc * c * (double)cout * k;          // Cin*Cout*k*Lin
+                if ((rc = si_launch_tapgemm(ctx, Ly.ups[i].math, p, st))) return rc;
+            }
+            if ((rc = si_tap(ctx, upn[i], U, (long)Bc * Lo * cout, st))) return rc;
+            // B3: multi-receptive-field fusion: mean over the resblocks, accumulated into xs by the last conv of each
+            for (int j = 0; j < nk; ++j) {
+                const ResW& R = Ly.rbs[(size_t)i * nk + j];
+                const int rk = d.rb_kernels[j];
+                const float* y = U;
+                for (int n = 0; n < d.num_dil; ++n) {
+                    const int dl = d.rb_dilations[j][n];
+                    float* t = buf[3];
+                    TapGemmParams p = gemm_params(ctx, R.c1[n]);
+                    p.x = y; p.out = t;
+                    p.nseg = Bc; p.Lin = (int)Lo; p.M = (int)Lo; p.ldx = cout; p.x_seg_stride = Lo * cout;
+                    p.dil = dl; p.pad = dl * (rk - 1) / 2; p.ldo = cout; p.o_seg_stride = Lo * cout; p.olimit = p.o_seg_stride;
+                    p.pro_slope = 0.1f;
+                    if ((rc = si_launch_tapgemm(ctx, R.c1[n].math, p, st))) return rc;
+                    const bool last = (n == d.num_dil - 1);
+                    float* ynext = last ? xs : buf[4 + (n & 1)];
+                    TapGemmParams q = gemm_params(ctx, R.c2[n]);
+                    q.x = t; q.out = ynext; q.res = y;
+                    q.nseg = Bc; q.Lin = (int)Lo; q.M = (int)Lo; q.ldx = cout; q.x_seg_stride = Lo * cout;
+                    q.dil = 1; q.pad = (rk - 1) / 2; q.ldo = cout; q.o_seg_stride = Lo * cout; q.olimit = q.o_seg_stride;
+                    q.pro_slope = 0.1f;
+                    if (last) { q.alpha = 1.0f / nk; q.accumulate = (j > 0); }
+                    if ((rc = si_launch_tapgemm(ctx, R.c2[n].math, q, st))) return rc;
+                    y = ynext;
+                }
+            }
+            if ((rc = si_tap(ctx, stn[i], xs, (long)Bc * Lo * cout, st))) return rc;
+            std::swap(x, xs);
+            Lc = Lo; c = cout;
+        }
+        // B4: leaky_relu(0.01) -> conv_post -> tanh
+        if ((rc = si_launch_conv_post(ctx, x, wf(ctx, Ly.post_w), wf(ctx, Ly.post_b), Bc, (int)Lc, c, 7, wav_out + (size_t)b0 * Lwav, st))) return rc;
+    }
+    return SI_OK;
+}
+
+int si_profile_start(si_ctx* ctx, int max_launches) {
+    if (!ctx || max_launches <= 0) return si_fail(ctx, SI_EINVAL, "si_profile_start: bad argument");
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    while (ctx->prof_pool.size() < (size_t)max_launches * 2) {
+        hipEvent_t e;
+        SI_HIP_CHECK(hipEventCreate(&e));
+        ctx->prof_pool.push_back(e);
+    }
+    ctx->prof_recs.clear();
+    ctx->prof_names.clear();
+    ctx->prof_used = 0;
+    ctx->prof_open = -1;
+    ctx->prof_on = true;
+    return SI_OK;
+}
+
+int si_profile_stop(si_ctx* ctx, si_profile_entry* out, int capacity, int* count) {
+    if (!ctx || !count) return si_fail(ctx, SI_EINVAL, "si_profile_stop: bad argument");
+    ctx->prof_on = false;
+    std::vector<si_profile_entry> agg(ctx->prof_names.size());
+    for (size_t i = 0; i < agg.size(); ++i) {
+        memset(&agg[i], 0, sizeof(si_profile_entry));
+        snprintf(agg[i].name, sizeof(agg[i].name), "%s", ctx->prof_names[i].c_str());
+    }
+    for (const auto& r : ctx->prof_recs) {
+        SI_HIP_CHECK(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        SI_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+        si_profile_entry& e = agg[r.name];
+        e.launches += 1; e.ms += ms; e.flops += r.flops; e.bytes += r.bytes;
+    }
+    *count = (int)agg.size();
+    for (int i = 0; i < (int)agg.size() && i < capacity && out; ++i) out[i] = agg[i];
+    ctx->prof_recs.clear();
+    ctx->prof_used = 0;
+    return SI_OK;
+}
+
+int si_debug_capture(si_ctx* ctx, const char* name, float* dst, long capacity) {
+    if (!ctx || !name) return SI_EINVAL;
+    if (!dst || capacity <= 0) ctx->dbg_capture.erase(name);
+    else ctx->dbg_capture[name] = {dst, capacity};
+    return SI_OK;
+}
+
+long si_debug_size(si_ctx* ctx, const char* name) {
+    if (!ctx || !name) return SI_EINVAL;
+    auto it = ctx->dbg_size.find(name);
+    if (it == ctx->dbg_size.end()) return si_fail(ctx, SI_EINVAL, "no intermediate named '%s' in the last forward", name);
+    return it->second;
+}
+
+}  // extern "C"

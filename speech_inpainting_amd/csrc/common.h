@@ -1,0 +1,104 @@
+// Internal declarations shared by the HIP translation units of libsi_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/si_hip.h"
+
+#define SI_HIP_CHECK(expr)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) return si_fail_hip(ctx, _e, #expr, __FILE__, __LINE__);           \
+    } while (0)
+
+int si_fail_hip(si_ctx* ctx, hipError_t e, const char* what, const char* file, int line);
+int si_fail(si_ctx* ctx, int code, const char* fmt, ...);
+// HIP-event bracket around one kernel launch (no-op unless si_profile_start armed the context)
+void si_prof_begin(si_ctx* ctx, const char* name, double flops, double bytes, hipStream_t st);
+void si_prof_end(si_ctx* ctx, hipStream_t st);
+
+typedef unsigned short bf16_t;   // raw bf16 bits
+
+// ------------------------------------------------------------------------------------------------
+// "Tap GEMM": every contraction of the path (Conv1d with stride/dilation/groups, ConvTranspose1d split
+// into stride phases, Linear) is
+//     out[seg][m][n] = epi( sum_tap sum_ci  pro(x[seg][m*stride + tap*dil - pad][g*Cin + ci]) * W[g][tap][n][ci] )
+// on channels-last activations, i.e. a GEMM whose A operand is a shifted view of the activation matrix.
+// ------------------------------------------------------------------------------------------------
+enum { SI_ACT_NONE = 0, SI_ACT_GELU = 1 };
+
+struct TapGemmParams {
+    const float* x;        // [nseg][Lin][ldx] fp32, channels-last
+    const void* w;         // [groups][ntaps][Npad][Cin]  (fp32, or bf16 hi plane)
+    const void* w_lo;      // bf16x3: lo plane, same layout
+    const float* bias;     // [groups*N] or nullptr
+    const float* res;      // residual, indexed like out, or nullptr
+    float* out;
+    int nseg, Lin, M;      // segments (clips), input rows and output rows per segment
+    int ldx;               // input row stride (floats)
+    long x_seg_stride;     // floats between segments
+    int Cin;               // input channels per group (multiple of BK)
+    int N, Npad;           // output columns per group, padded row count of W
+    int ntaps, stride, dil, pad;
+    int groups;
+    int ldo;               // output row stride (floats)
+    long o_seg_stride;
+    long ooff;             // flat offset added to m*ldo + n (ConvTranspose phase layout: -pad*Cout)
+    long olimit;           // stores outside [0, olimit) of a segment are dropped
+    float pro_slope;       // leaky-relu slope applied to x while staging (1 = identity)
+    int act;               // SI_ACT_*
+    float alpha;           // v = (acc + bias -> act -> + res) * alpha
+    int accumulate;        // out = v + out
+    double algo_macs;      // algorithmic multiply-accumulates of the layer (0: derive from the GEMM shape)
+};
+
+// N-tile width the launcher uses for a given N; the packer pads W rows to a multiple of it.
+static inline int si_pick_bn(int N) { return N >= 128 ? 128 : (N > 32 ? 64 : 32); }
+static inline int si_round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------
+// encoder kernels (encoder_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+struct WaveNormParams {           // A0 + A1 (group-norm flavour)
+    const float* wav;             // (B, N) raw
+    const int32_t* mask_start;    // (B) or null
+    const int32_t* mask_len;      // (B) or null
+    int B, N, L1;                 // L1 = conv0 output length
+    int C, K, S;                  // conv0 channels / kernel / stride
+    int normalize;                // 0: wav is already zero-mean/unit-variance
+};
+
+int si_launch_wave_stats(si_ctx* ctx, const WaveNormParams& p, double* stats /*B*2: mean, rstd*/, hipStream_t st);
+// conv0 -> GroupNorm(C groups) -> GELU, channels-last out (B, L1, C)
+int si_launch_conv0_groupnorm(si_ctx* ctx, const WaveNormParams& p, const double* stats, const float* w /*[C][K]*/,
+                              const float* gamma, const float* beta, double* partials, float* affine, float* out,
+                              hipStream_t st);
+// conv0 (+bias) only, channels-last out, for the layer-norm flavour (LN+GELU applied by si_launch_layernorm)
+int si_launch_conv0_affine(si_ctx* ctx, const WaveNormParams& p, const double* stats, const float* w, const float* bias,
+                           float* affine, float* out, hipStream_t st);
+size_t si_conv0_partials_bytes(int B, int N);
+
+// y = LN(x [+ add]) * gamma + beta over the last dim C (rows x C), optional GELU afterwards
+int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const float* gamma, const float* beta, float* y,
+                        long rows, int C, float eps, int gelu, hipStream_t st);
+
+// softmax(q k^T / sqrt(64)) v for head_dim 64; qkv (B, T, 3H) packed [q | k | v]; out (B, T, H)
+int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st);
+
+// cosine arg-max against centred centroids + splice of the raw centroid into mel (A10..A13)
+int si_launch_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,
+                              const float* cb_centered /*K x D*/, const float* cb_raw /*K x D*/,
+                              const float* cb_rnorm /*K*/, int K, float* mel, int Tm, int64_t* labels, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------
+// vocoder kernels (vocoder_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+// mel (B, D, Tm) channels-first -> (B, Tout, ldo) channels-last, time-stretched (stretch=1) or copied;
+// channels D..ldo-1 are written as zero.
+int si_launch_extend_mel(si_ctx* ctx, const float* mel, int B, int D, int Tm, int Tout, int stretch, float* out, int ldo,
+                         hipStream_t st);
+// leaky_relu(0.01) -> Conv1d(C -> 1, k, pad k/2) -> tanh ; x (B, L, C) channels-last -> wav (B, L)
+int si_launch_conv_post(si_ctx* ctx, const float* x, const float* w /*[k][C]*/, const float* bias, int B, int L, int C, int k,
+                        float* wav, hipStream_t st);

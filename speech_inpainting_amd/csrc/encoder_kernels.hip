@@ -1,0 +1,501 @@
+// encoder_kernels.hip -- the non-GEMM kernels of the HuBERT half of the path (gfx950, wave64).
+//
+//  * wave_stats / conv0 family : zero-mask + zero-mean/unit-variance normalise (I_ea/predict.py:132-141)
+//    fused into the load of conv0 -> GroupNorm(C groups) -> GELU (modeling_hubert.py:154-175).
+//    GroupNorm over time needs per-(clip, channel) mean/variance of the conv output.  Because conv0 has ONE
+//    input channel, those are quadratic forms of the clip's K-lag autocorrelation:
+//        sum_t y_c[t]   = sum_k w[c][k] * S[k],          S[k]    = sum_t x[s*t+k]
+//        sum_t y_c[t]^2 = sum_kk' w[c][k] w[c][k'] R[kk'], R[kk'] = sum_t x[s*t+k] x[s*t+k']
+//    so the statistics cost one pass over the 256 KB clip (in fp64) instead of a pass over the 26 MB conv
+//    output, and the big tensor is written exactly once, already normalised and activated (HBM-bound row A1).
+//  * layernorm : one wave per row, two-pass in registers, wave shuffles for the reductions.
+//  * attention : flash-style exact-fp32 attention on v_mfma_f32_32x32x2_f32 with the "keys on the accumulator
+//    rows" orientation: S^T = K Q^T leaves each lane holding one query's scores, so the softmax needs one
+//    cross-half exchange, and the S^T accumulator registers ARE the B operand of O^T = V^T P^T (no LDS
+//    round trip, no shuffles; cdna_hip_programming.md section 3 "An accumulator tile as the next MFMA's operand").
+//  * codebook_splice : cosine arg-max against centred centroids + raw-centroid splice (I_ea/loss_fn.py:44-47,
+//    I_ea/predict.py:164-168,184-187).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ A0
+// stats[b] = {mean, 1/sqrt(var + 1e-7)} of the zero-masked clip, accumulated in fp64.
+__global__ __launch_bounds__(1024) void wave_stats_kernel(WaveNormParams p, double* __restrict__ stats) {
+    const int b = blockIdx.x;
+    if (!p.normalize) {
+        if (threadIdx.x == 0) { stats[2 * b] = 0.0; stats[2 * b + 1] = 1.0; }
+        return;
+    }
+    const float* x = p.wav + (long)b * p.N;
+    const int ms = p.mask_start ? p.mask_start[b] : 0;
+    const int ml = p.mask_len ? p.mask_len[b] : 0;
+    double s = 0.0, ss = 0.0;
+    for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
+        float v = x[i];
+        if (i >= ms && i < ms + ml) v = 0.f;
+        s += v;
+        ss += (double)v * v;
+    }
+    __shared__ double red[2][16];
+    s = wave_sum_d(s);
+    ss = wave_sum_d(ss);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[0][w] = s; red[1][w] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S = 0, SS = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { S += red[0][i]; SS += red[1][i]; }
+        const double mean = S / p.N;
+        double var = SS / p.N - mean * mean;
+        if (var < 0) var = 0;
+        stats[2 * b] = mean;
+        stats[2 * b + 1] = 1.0 / sqrt(var + 1e-7);
+    }
+}
+
+__device__ __forceinline__ float load_norm(const float* x, int i, int ms, int ml, float mean, float rstd) {
+    float v = x[i];
+    if (i >= ms && i < ms + ml) v = 0.f;
+    return (v - mean) * rstd;
+}
+
+// partials[b][chunk][NP]: NP = K + K(K+1)/2 lag sums of the normalised clip over the chunk's conv positions.
+#define SI_C0_TCH 512
+__global__ __launch_bounds__(256) void conv0_lagsums_kernel(WaveNormParams p, const double* __restrict__ stats,
+                                                            double* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);                       // S*TCH + K
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int nchunks = gridDim.x;
+    const int t0 = chunk * SI_C0_TCH;
+    const int nt = min(SI_C0_TCH, p.L1 - t0);
+    const int K = p.K, S = p.S;
+    const int NP = K + K * (K + 1) / 2;
+    const float mean = (float)stats[2 * b], rstd = (float)stats[2 * b + 1];
+    const int ms = p.mask_start ? p.mask_start[b] : 0, ml = p.mask_len ? p.mask_len[b] : 0;
+    const float* x = p.wav + (long)b * p.N;
+    const int win = (nt - 1) * S + K;
+    for (int i = threadIdx.x; i < win; i += 256) xs[i] = load_norm(x, t0 * S + i, ms, ml, mean, rstd);
+    __syncthreads();
+    __shared__ double part[2][160];
+    const int pr = threadIdx.x & 127, half = threadIdx.x >> 7;
+    double acc = 0.0;
+    if (pr < NP) {
+        int k0, k1;
+        if (pr < K) { k0 = pr; k1 = -1; }
+        else {                                  // pair index -> (k0 <= k1)
+            int q = pr - K; k0 = 0;
+            while (q >= K - k0) { q -= K - k0; ++k0; }
+            k1 = k0 + q;
+        }
+        for (int t = half; t < nt; t += 2) {
+            const float a = xs[t * S + k0];
+            acc += (k1 < 0) ? (double)a : (double)a * (double)xs[t * S + k1];
+        }
+        part[half][pr] = acc;
+    }
+    __syncthreads();
+    if (half == 0 && pr < NP) partials[((long)b * nchunks + chunk) * NP + pr] = part[0][pr] + part[1][pr];
+}
+
+// affine[b][c] = {a, sh}:  y = gelu(a * conv + sh)  with a = gamma*rstd_c, sh = beta - mean_c*a
+__global__ __launch_bounds__(256) void conv0_gn_affine_kernel(WaveNormParams p, const double* __restrict__ partials, int nchunks,
+                                                              const float* __restrict__ w, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ affine) {
+    __shared__ double tot[160];
+    const int b = blockIdx.x;
+    const int K = p.K, NP = K + K * (K + 1) / 2;
+    if ((int)threadIdx.x < NP) {
+        double s = 0.0;
+        for (int c = 0; c < nchunks; ++c) s += partials[((long)b * nchunks + c) * NP + threadIdx.x];   // fixed order
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+        const float* wc = w + (long)c * K;
+        double m = 0.0, e2 = 0.0;
+        for (int k = 0; k < K; ++k) m += (double)wc[k] * tot[k];
+        int q = K;
+        for (int k0 = 0; k0 < K; ++k0)
+            for (int k1 = k0; k1 < K; ++k1, ++q)
+                e2 += (k0 == k1 ? 1.0 : 2.0) * (double)wc[k0] * (double)wc[k1] * tot[q];
+        m /= p.L1;
+        double var = e2 / p.L1 - m * m;
+        if (var < 0) var = 0;
+        const double rstd = 1.0 / sqrt(var + 1e-5);
+        const double a = (double)gamma[c] * rstd;
+        affine[((long)b * p.C + c) * 2] = (float)a;
+        affine[((long)b * p.C + c) * 2 + 1] = (float)((double)beta[c] - m * a);
+    }
+}
+
+__global__ void conv0_bias_affine_kernel(int B, int C, const float* __restrict__ bias, float* __restrict__ affine) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * C) { affine[2 * i] = 1.f; affine[2 * i + 1] = bias ? bias[i % C] : 0.f; }
+}
+
+// out[b][t][c] = act(a[b][c] * sum_k w[c][k] * xhat[b][s*t+k] + sh[b][c]); channels-last, written once.
+#define SI_C0_ROWS 64
+template <int K, bool GELU>
+__global__ __launch_bounds__(256) void conv0_apply_kernel(WaveNormParams p, const double* __restrict__ stats,
+                                                          const float* __restrict__ w, const float* __restrict__ affine,
+                                                          float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * SI_C0_ROWS;
+    const int nt = min(SI_C0_ROWS, p.L1 - t0);
+    const int S = p.S, C = p.C;
+    const float mean = (float)stats[2 * b], rstd = (float)stats[2 * b + 1];
+    const int ms = p.mask_start ? p.mask_start[b] : 0, ml = p.mask_len ? p.mask_len[b] : 0;
+    const float* x = p.wav + (long)b * p.N;
+    const int win = (nt - 1) * S + K;
+    for (int i = threadIdx.x; i < win; i += 256) xs[i] = load_norm(x, t0 * S + i, ms, ml, mean, rstd);
+    __syncthreads();
+    const int tpr = C / 4;                       // threads per output row (float4 of channels each)
+    const int rpp = 256 / tpr;                   // rows per pass
+    const int c4 = (threadIdx.x % tpr) * 4;
+    const int r0 = threadIdx.x / tpr;
+    float wr[4][K];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < K; ++k) wr[e][k] = w[(long)(c4 + e) * K + k];
+    float av[4], sv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        av[e] = affine[((long)b * C + c4 + e) * 2];
+        sv[e] = affine[((long)b * C + c4 + e) * 2 + 1];
+    }
+    for (int r = r0; r < nt; r += rpp) {
+        float xv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) xv[k] = xs[r * S + k];
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc = fmaf(wr[e][k], xv[k], acc);
+            float v = fmaf(av[e], acc, sv[e]);
+            y[e] = GELU ? gelu_erf(v) : v;
+        }
+        *reinterpret_cast<f32x4*>(out + ((long)b * p.L1 + t0 + r) * C + c4) = y;
+    }
+}
+
+size_t si_conv0_partials_bytes(int B, int N) {
+    // upper bound on chunks: L1 <= N
+    const long nchunks = ((long)N + SI_C0_TCH - 1) / SI_C0_TCH + 1;
+    return (size_t)B * nchunks * 160 * sizeof(double);
+}
+
+static int conv0_check(si_ctx* ctx, const WaveNormParams& p) {
+    if (p.K != 10) return si_fail(ctx, SI_EINVAL, "conv0 kernel size %d unsupported (HuBERT uses 10)", p.K);
+    const int tpr = p.C / 4;
+    if (p.C % 4 != 0 || tpr > 256 || (256 % tpr) != 0)
+        return si_fail(ctx, SI_EINVAL, "conv0 channel count %d must be 4*2^j <= 1024", p.C);
+    return SI_OK;
+}
+
+int si_launch_wave_stats(si_ctx* ctx, const WaveNormParams& p, double* stats, hipStream_t st) {
+    si_prof_begin(ctx, "wave_stats", 3.0 * p.B * p.N, 4.0 * p.B * p.N, st);
+    hipLaunchKernelGGL(wave_stats_kernel, dim3(p.B), dim3(1024), 0, st, p, stats);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
+static int conv0_apply(si_ctx* ctx, const WaveNormParams& p, const double* stats, const float* w, const float* affine,
+                       float* out, bool gelu, hipStream_t st) {
+    dim3 grid((p.L1 + SI_C0_ROWS - 1) / SI_C0_ROWS, p.B);
+    const size_t lds = ((size_t)(SI_C0_ROWS - 1) * p.S + p.K) * sizeof(float);
+    si_prof_begin(ctx, "conv0_apply", 2.0 * p.B * p.L1 * (double)p.C * p.K, 4.0 * p.B * ((double)p.N + (double)p.L1 * p.C), st);
+    if (gelu) hipLaunchKernelGGL((conv0_apply_kernel<10, true>), grid, dim3(256), lds, st, p, stats, w, affine, out);
+    else hipLaunchKernelGGL((conv0_apply_kernel<10, false>), grid, dim3(256), lds, st, p, stats, w, affine, out);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
+int si_launch_conv0_groupnorm(si_ctx* ctx, const WaveNormParams& p, const double* stats, const float* w, const float* gamma,
+                              const float* beta, double* partials, float* affine, float* out, hipStream_t st) {
+    int rc = conv0_check(ctx, p);
+    if (rc) return rc;
+    const int nchunks = (p.L1 + SI_C0_TCH - 1) / SI_C0_TCH;
+    const size_t lds = ((size_t)(SI_C0_TCH - 1) * p.S + p.K) * sizeof(float);
+    si_prof_begin(ctx, "conv0_lagsums", 2.0 * p.B * p.L1 * 65.0, 4.0 * p.B * p.N, st);
+    hipLaunchKernelGGL(conv0_lagsums_kernel, dim3(nchunks, p.B), dim3(256), lds, st, p, stats, partials);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    si_prof_begin(ctx, "conv0_gn_affine", 2.0 * p.B * p.C * 65.0, 8.0 * p.B * p.C, st);
+    hipLaunchKernelGGL(conv0_gn_affine_kernel, dim3(p.B), dim3(256), 0, st, p, partials, nchunks, w, gamma, beta, affine);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return conv0_apply(ctx, p, stats, w, affine, out, true, st);
+}
+
+// plain flavour with an explicit affine scratch (used by the layer-norm feature extractor)
+int si_launch_conv0_affine(si_ctx* ctx, const WaveNormParams& p, const double* stats, const float* w, const float* bias,
+                           float* affine, float* out, hipStream_t st) {
+    int rc = conv0_check(ctx, p);
+    if (rc) return rc;
+    const int n = p.B * p.C;
+    hipLaunchKernelGGL(conv0_bias_affine_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p.B, p.C, bias, affine);
+    SI_HIP_CHECK(hipGetLastError());
+    return conv0_apply(ctx, p, stats, w, affine, out, false, st);
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// One wave per row.  C % 4 == 0, C <= 2048 (the row lives in 8 float4 registers per lane).
+template <bool GELU>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ y, long rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    const float* ar = add ? add + row * C : nullptr;
+    f32x4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = (j * 64 + lane) * 4;
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < C) {
+            v[j] = *reinterpret_cast<const f32x4*>(xr + i);
+            if (ar) v[j] += *reinterpret_cast<const f32x4*>(ar + i);
+            s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+        }
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = (j * 64 + lane) * 4;
+        if (i < C) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    float* yr = y + row * C;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = (j * 64 + lane) * 4;
+        if (i < C) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + i);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = (v[j][e] - mean) * rstd * g[e] + bt[e];
+                o[e] = GELU ? gelu_erf(t) : t;
+            }
+            *reinterpret_cast<f32x4*>(yr + i) = o;
+        }
+    }
+}
+
+int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const float* gamma, const float* beta, float* y,
+                        long rows, int C, float eps, int gelu, hipStream_t st) {
+    if (C % 4 != 0 || C > 2048) return si_fail(ctx, SI_EINVAL, "layernorm width %d must be a multiple of 4 and <= 2048", C);
+    if (rows <= 0) return SI_OK;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    si_prof_begin(ctx, "layernorm", 8.0 * rows * C, 8.0 * rows * C, st);
+    if (gelu) hipLaunchKernelGGL(layernorm_kernel<true>, grid, dim3(256), 0, st, x, add, gamma, beta, y, rows, C, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<false>, grid, dim3(256), 0, st, x, add, gamma, beta, y, rows, C, eps);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+// head_dim = 64.  Workgroup = 4 waves = 128 queries of one (clip, head); wave = 32 queries.  Keys/values stream
+// through LDS in tiles of 32.  Per tile and wave:
+//   S^T[key][q] = sum_d K[key][d] * Q[q][d]/8      A = K tile rows (LDS, b128), B = Q row kept in 32 registers
+//   online softmax down each lane's column (query = lane&31): in-lane over 16 registers + one lane^32 exchange
+//   O^T[d][q] += sum_key V[key][d] * P^T[key][q]   A = V tile (LDS, b32), B = the S^T accumulator registers:
+//     MFMA step s reads key (s&3)+8*(s>>2)+4*(lane>>5) from both operands, which is exactly the key whose score
+//     register s of this lane holds (C/D row map of the 32x32 MFMA).
+#define ATT_KT 32
+#define ATT_LD 68     // 64 + 4 floats: 16-B aligned rows, consecutive rows shift by 4 banks
+
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int H,
+                                                        int heads) {
+    __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * ATT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const long ld = 3L * H;
+    const float* base = qkv + (long)b * T * ld + h * 64;
+
+    // this lane's half of its query row, pre-scaled by head_dim^-0.5 = 2^-3 (exact)
+    float qr[32];
+    {
+        const int qrow = min(q0 + l31, T - 1);
+        const float* qp = base + (long)qrow * ld + half * 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(qp + 4 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qr[4 * j + e] = t[e] * 0.125f;
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float mrun = -INFINITY, lrun = 0.f;
+
+    for (int k0 = 0; k0 < T; k0 += ATT_KT) {
+        __syncthreads();
+        // stage K and V tiles: 32 rows x 64 floats each; 256 threads x 2 float4 per matrix
+        for (int idx = tid; idx < ATT_KT * 16; idx += 256) {
+            const int r = idx >> 4, j = idx & 15;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + r < T) {
+                const float* rp = base + (long)(k0 + r) * ld;
+                kv = *reinterpret_cast<const f32x4*>(rp + H + 4 * j);
+                vv = *reinterpret_cast<const f32x4*>(rp + 2 * H + 4 * j);
+            }
+            *reinterpret_cast<f32x4*>(Ks + r * ATT_LD + 4 * j) = kv;
+            *reinterpret_cast<f32x4*>(Vs + r * ATT_LD + 4 * j) = vv;
+        }
+        __syncthreads();
+        // S^T tile
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const float* kp = Ks + l31 * ATT_LD + half * 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(kp + 4 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], qr[4 * j + e], s, 0, 0, 0);
+        }
+        // mask keys beyond T, column max
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (key >= T) s[r] = -INFINITY;
+            tmax = fmaxf(tmax, s[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mrun, tmax);              // finite: every tile holds at least key k0 < T
+        const float alpha = __expf(mrun - mnew);           // exp(-inf) = 0 on the first tile
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - mnew); psum += s[r]; }
+        psum += __shfl_xor(psum, 32, 64);
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        // O^T += V^T P^T
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int krow = (st & 3) + 8 * (st >> 2) + 4 * half;
+            const float v0 = Vs[krow * ATT_LD + l31];
+            const float v1 = Vs[krow * ATT_LD + 32 + l31];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[st], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[st], o1, 0, 0, 0);
+        }
+    }
+    // O^T[d][q]: column = lane&31 = query, rows d = (r&3) + 8*(r>>2) + 4*half (+32 for o1)
+    const int q = q0 + l31;
+    if (q < T) {
+        const float inv = 1.0f / lrun;
+        float* op = out + ((long)b * T + q) * H + h * 64;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = 8 * g4 + 4 * half;
+            f32x4 a = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
+            f32x4 c = {o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv};
+            *reinterpret_cast<f32x4*>(op + d) = a;
+            *reinterpret_cast<f32x4*>(op + 32 + d) = c;
+        }
+    }
+}
+
+int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st) {
+    if (heads <= 0 || H != heads * 64) return si_fail(ctx, SI_EINVAL, "attention kernel needs head_dim 64 (H=%d heads=%d)", H, heads);
+    if (B <= 0 || T <= 0) return SI_OK;
+    dim3 grid((T + 127) / 128, B * heads);
+    si_prof_begin(ctx, "attention_f32", 4.0 * B * (double)T * T * H, 16.0 * B * T * H, st);   // 2*T^2*H MACs (QK^T + PV)
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, qkv, out, T, H, heads);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ codebook
+// One workgroup per (clip, masked frame).  D <= 128.
+__global__ __launch_bounds__(128) void codebook_splice_kernel(const float* __restrict__ feats, int T, int D,
+                                                              const int32_t* __restrict__ frame_pos, int Lm,
+                                                              const float* __restrict__ cc, const float* __restrict__ raw,
+                                                              const float* __restrict__ rnorm, int K, float* __restrict__ mel,
+                                                              int Tm, int64_t* __restrict__ labels) {
+    __shared__ float v[128];
+    __shared__ float bs[2];
+    __shared__ int bi[2];
+    const int b = blockIdx.y, j = blockIdx.x;
+    const int pos = frame_pos[b] + j;
+    if (pos < 0 || pos >= T) return;                                 // uniform per block
+    const float* f = feats + ((long)b * T + pos) * D;
+    if ((int)threadIdx.x < D) v[threadIdx.x] = f[threadIdx.x];
+    __syncthreads();
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int k = threadIdx.x; k < K; k += 128) {
+        const float* c = cc + (long)k * D;
+        float dot = 0.f;
+        for (int d = 0; d < D; ++d) dot = fmaf(v[d], c[d], dot);
+        const float sim = dot * rnorm[k];                            // ||v|| is common to all k
+        if (sim > best) { best = sim; besti = k; }                   // ascending k per thread: first max wins
+    }
+    // wave arg-max (ties -> lowest index, torch.argmax returns the first maximum)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bs[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; }
+    __syncthreads();
+    int lab = bi[0];
+    if (bs[1] > bs[0] || (bs[1] == bs[0] && bi[1] < bi[0])) lab = bi[1];
+    if (threadIdx.x == 0 && labels) labels[(long)b * Lm + j] = lab;
+    if (pos < Tm && (int)threadIdx.x < D) mel[((long)b * D + threadIdx.x) * Tm + pos] = raw[(long)lab * D + threadIdx.x];
+}
+
+int si_launch_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,
+                              const float* cb_centered, const float* cb_raw, const float* cb_rnorm, int K, float* mel, int Tm,
+                              int64_t* labels, hipStream_t st) {
+    if (D > 128) return si_fail(ctx, SI_EINVAL, "codebook dim %d > 128", D);
+    if (B <= 0 || Lm <= 0) return SI_OK;
+    si_prof_begin(ctx, "codebook_splice", 2.0 * B * Lm * (double)K * D, 4.0 * B * Lm * 2.0 * D, st);
+    hipLaunchKernelGGL(codebook_splice_kernel, dim3(Lm, B), dim3(128), 0, st, feats, T, D, frame_pos, Lm, cb_centered, cb_raw,
+                       cb_rnorm, K, mel, Tm, labels);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}

@@ -1,0 +1,96 @@
+// vocoder_kernels.hip -- the non-GEMM kernels of the HiFi-GAN half of the path (gfx950, wave64).
+//  * extend_mel : time-only bilinear stretch x441/256, align_corners=False
+//                 (I_ea/hifi_gan/inference_modified.py:16-19), fused with the channels-first -> channels-last
+//                 transpose the generator kernels want; channel padding written as zeros.
+//  * conv_post  : leaky_relu(0.01) -> Conv1d(C -> 1, k=7, pad 3) -> tanh (I_ea/hifi_gan/models.py:119-121),
+//                 the tail of the generator: 1 output channel, so it is a per-sample dot product, not a GEMM.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void extend_mel_kernel(const float* __restrict__ mel, int D, int Tm, int Tout, int stretch,
+                                                         float rscale, float* __restrict__ out, int ldo) {
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)Tout * ldo) return;
+    const int t = (int)(i / ldo), c = (int)(i - (long)t * ldo);
+    float v = 0.f;
+    if (c < D) {
+        const float* row = mel + ((long)b * D + c) * Tm;
+        if (stretch) {
+            // ATen area_pixel_compute_source_index: one fused multiply-add in fp32, clamped at 0
+            float src = fmaf((float)t + 0.5f, rscale, -0.5f);
+            src = src < 0.f ? 0.f : src;
+            int i0 = (int)floorf(src);
+            if (i0 > Tm - 1) i0 = Tm - 1;
+            const int i1 = i0 + 1 < Tm ? i0 + 1 : Tm - 1;
+            float l1 = src - (float)i0;
+            l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+            const float l0 = 1.f - l1;
+            v = l0 * row[i0] + l1 * row[i1];
+        } else {
+            v = row[t];
+        }
+    }
+    out[(long)b * Tout * ldo + i] = v;
+}
+
+int si_launch_extend_mel(si_ctx* ctx, const float* mel, int B, int D, int Tm, int Tout, int stretch, float* out, int ldo,
+                         hipStream_t st) {
+    if (B <= 0 || Tout <= 0) return SI_OK;
+    const float rscale = (float)(1.0 / (441.0 / 256.0));
+    dim3 grid((unsigned)(((long)Tout * ldo + 255) / 256), B);
+    si_prof_begin(ctx, "extend_mel", 3.0 * B * Tout * D, 4.0 * B * D * ((double)Tm + Tout), st);
+    hipLaunchKernelGGL(extend_mel_kernel, grid, dim3(256), 0, st, mel, D, Tm, Tout, stretch, rscale, out, ldo);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
+// 256 output samples per workgroup; the (256 + k - 1) x C input rows are staged (with the leaky-relu applied)
+// into LDS with an odd row stride so the per-lane row walks are bank-conflict free.
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, int L, int C, int k,
+                                                        float* __restrict__ wav) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);              // [(256 + k - 1)][C + 1]
+    float* ws = xs + (256 + k - 1) * (C + 1);                // [k][C]
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * 256;
+    const int pad = k / 2;
+    const int rows = 256 + k - 1;
+    const int c4n = C / 4;
+    const float* xb = x + (long)b * L * C;
+    for (int idx = threadIdx.x; idx < rows * c4n; idx += 256) {
+        const int r = idx / c4n, j = idx - r * c4n;
+        const int t = t0 - pad + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < L) v = *reinterpret_cast<const f32x4*>(xb + (long)t * C + 4 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xs[r * (C + 1) + 4 * j + e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+    }
+    for (int idx = threadIdx.x; idx < k * C; idx += 256) ws[idx] = w[idx];
+    __syncthreads();
+    const int t = t0 + threadIdx.x;
+    if (t >= L) return;
+    float acc = bias[0];
+    for (int kk = 0; kk < k; ++kk) {
+        const float* xr = xs + (threadIdx.x + kk) * (C + 1);
+        const float* wr = ws + kk * C;
+        for (int c = 0; c < C; ++c) acc = fmaf(xr[c], wr[c], acc);
+    }
+    wav[(long)b * L + t] = tanhf(acc);
+}
+
+int si_launch_conv_post(si_ctx* ctx, const float* x, const float* w, const float* bias, int B, int L, int C, int k, float* wav,
+                        hipStream_t st) {
+    if (C % 4 != 0) return si_fail(ctx, SI_EINVAL, "conv_post: C=%d must be a multiple of 4", C);
+    if (B <= 0 || L <= 0) return SI_OK;
+    const size_t lds = ((size_t)(256 + k - 1) * (C + 1) + (size_t)k * C) * sizeof(float);
+    dim3 grid((L + 255) / 256, B);
+    si_prof_begin(ctx, "conv_post", 2.0 * B * L * (double)C * k, 4.0 * B * L * (C + 1.0), st);
+    hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), lds, st, x, w, bias, L, C, k, wav);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}

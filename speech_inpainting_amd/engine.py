@@ -1,0 +1,145 @@
+"""Host-side mirror of the reference's module interface over the HIP library.
+
+The reference's seam is Python duck-typing at three calls; the classes below keep those
+names, argument meanings and shapes, and forward to libsi_hip.so:
+
+    model(input_values (B, N), attention_mask)      -> (B, T, 80)        I_ea/model.py:80-89
+    generator(feats (B, 80, T'))                     -> (B, 1, T' * 256)  I_ea/hifi_gan/models.py:107-123
+    loss.cos_sim(values, labels)[1]                  -> predicted labels  I_ea/loss_fn.py:44-47
+
+plus `InpaintingEngine.predict_batch`, the batched form of the script body I_ea/predict.py:130-207, which is what the
+benchmark times.  Nothing here computes on the CPU: a missing library or a CPU device raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, Mapping, Optional, Sequence
+
+import torch
+
+from .arch import HubertArch, VocoderArch
+from .checkpoint import flatten_checkpoint
+from .native import NativeContext, make_desc
+
+
+def mask_samples_from_frames(frame_pos: int, frame_len: int):
+    """Sample span zeroed for a frame-level mask: [pos*320+80, (pos+len)*320+79-80) (I_ea/predict.py:133)."""
+    s = frame_pos * 320 + 80
+    e = (frame_pos + frame_len) * 320 + 79 - 80
+    return s, max(e - s, 0)
+
+
+class InpaintingEngine:
+    """One model pair (HuBERT + head, codebook, HiFi-GAN generator) resident on one GPU."""
+
+    def __init__(self, harch: HubertArch, varch: VocoderArch, num_clusters: int, device="cuda:0",
+                 encoder_dtype: str = "fp32", vocoder_dtype: str = "fp32", vocoder_chunk: int = 0):
+        self.harch, self.varch = harch, varch
+        self.device = torch.device(device)
+        self.encoder_dtype, self.vocoder_dtype = encoder_dtype, vocoder_dtype
+        self.ctx = NativeContext(make_desc(harch, varch, num_clusters, encoder_dtype, vocoder_dtype, vocoder_chunk), self.device)
+
+    # ---- weights
+    def load_state(self, hubert_sd: Mapping[str, torch.Tensor], gen_sd: Mapping[str, torch.Tensor], codebook: torch.Tensor):
+        blob, index = flatten_checkpoint(hubert_sd, gen_sd, codebook)
+        self.ctx.load_weights(blob, index)
+        return self
+
+    def alloc_weights(self):
+        self.ctx.alloc_weights()
+        return self
+
+    def weights_tensor(self) -> torch.Tensor:
+        return self.ctx.weights_tensor()
+
+    # ---- the three stages
+    def encode(self, wave16: torch.Tensor, mask_start: Optional[torch.Tensor] = None, mask_len: Optional[torch.Tensor] = None,
+               normalize: bool = True) -> torch.Tensor:
+        return self.ctx.hubert_forward(wave16, mask_start, mask_len, normalize)
+
+    def splice(self, feats: torch.Tensor, frame_pos: torch.Tensor, lm: int, mel: torch.Tensor) -> torch.Tensor:
+        return self.ctx.codebook_splice(feats, frame_pos, lm, mel)
+
+    def vocode(self, mel: torch.Tensor, stretch: bool = True) -> torch.Tensor:
+        return self.ctx.hifigan_forward(mel, stretch)
+
+    def predict_batch(self, wave16: torch.Tensor, mel: torch.Tensor, frame_pos: torch.Tensor, frame_len: int,
+                      blind: bool = False, mask_start: Optional[torch.Tensor] = None,
+                      mask_len: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """wave16 (B, N) raw 16 kHz clips, mel (B, 80, Tm) log-mel of the masked 22.05 kHz clips, frame_pos (B,) int32
+        first masked 20 ms frame, frame_len = Lm.  All tensors on this engine's GPU.  `mel` is not modified.
+        blind=True replaces every frame (mask position unknown)."""
+        B = wave16.shape[0]
+        if blind:
+            feats = self.encode(wave16, None, None)
+            pos = torch.zeros(B, dtype=torch.int32, device=self.device)
+            lm = min(feats.shape[1], mel.shape[2])
+        else:
+            if mask_start is None:
+                mask_start = frame_pos * 320 + 80                                   # predict.py:133
+                mask_len = torch.full_like(frame_pos, max(frame_len * 320 - 81, 0))
+            feats = self.encode(wave16, mask_start.to(torch.int32), mask_len.to(torch.int32))
+            pos, lm = frame_pos, frame_len
+        mel2 = mel.clone()
+        labels = self.splice(feats, pos, lm, mel2)
+        wav = self.vocode(mel2, stretch=True)
+        return {"feats": feats, "labels": labels, "mel": mel2, "wave": wav}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Drop-in module wrappers (same call signatures as the reference's nn.Modules)
+# ------------------------------------------------------------------------------------------------------------------
+class CustomModel:
+    """`CustomModel.forward` (I_ea/model.py:80-89): processor-normalised input_values (B, N) -> (B, T, codebook_dim).
+    attention_mask must be all ones (every BASELINE config uses full-length clips; padded batches are bucketed by
+    exact length instead)."""
+
+    def __init__(self, engine: InpaintingEngine):
+        self.engine = engine
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.engine.device:
+            raise RuntimeError("the engine is bound to its GPU at construction")
+        return self
+
+    def __call__(self, input_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if attention_mask is not None and not bool(attention_mask.bool().all()):
+            raise NotImplementedError("padded batches are not supported; group clips by exact length")
+        x = input_values.to(self.engine.device, torch.float32).contiguous()
+        return self.engine.encode(x, None, None, normalize=False)
+
+    forward = __call__
+
+
+class Generator:
+    """`Generator.forward` (I_ea/hifi_gan/models.py:107-123): feats (B, 80, T') -> (B, 1, T' * hop)."""
+
+    def __init__(self, engine: InpaintingEngine):
+        self.engine = engine
+
+    def eval(self):
+        return self
+
+    def remove_weight_norm(self):
+        return None            # folded at load (api.hip)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.to(self.engine.device, torch.float32).contiguous()
+        return self.engine.vocode(x, stretch=False).unsqueeze(1)
+
+    forward = __call__
+
+
+class LossFunction:
+    """The arg-max half of `LossFunction.cos_sim` (I_ea/loss_fn.py:44-47) plus the centroid splice that follows it
+    in the script (I_ea/predict.py:184-187)."""
+
+    def __init__(self, engine: InpaintingEngine):
+        self.engine = engine
+
+    def predict_and_splice(self, outputs: torch.Tensor, mask_pos: torch.Tensor, mask_len: int, mel: torch.Tensor):
+        """outputs (B, T, 80), mask_pos (B,) int32, mel (B, 80, Tm) modified in place -> labels (B, Lm)."""
+        return self.engine.splice(outputs.contiguous(), mask_pos.to(self.engine.device, torch.int32).contiguous(),
+                                  int(mask_len), mel)

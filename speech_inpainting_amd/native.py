@@ -1,0 +1,288 @@
+"""ctypes binding of libsi_hip.so (include/si_hip.h).
+
+PyTorch is only plumbing here: it owns device memory (inputs, outputs, workspace) and the HIP stream.
+There is no CPU fallback: if the shared library is absent, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .arch import HubertArch, VocoderArch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsi_hip.so")
+
+SI_MATH = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2}
+SI_MAX_CONV, SI_MAX_UPS, SI_MAX_RB, SI_MAX_DIL = 8, 8, 4, 4
+
+EXPORTS = ["si_version", "si_create", "si_destroy", "si_last_error", "si_load_weights", "si_alloc_weights",
+           "si_weights_device_ptr", "si_workspace_bytes", "si_hubert_forward", "si_codebook_splice",
+           "si_hifigan_forward", "si_num_frames", "si_vocoder_samples", "si_profile_start", "si_profile_stop",
+           "si_debug_capture", "si_debug_size"]
+
+
+class ProfileEntry(C.Structure):
+    """Mirror of si_profile_entry."""
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("reserved", C.c_int32),
+                ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+class ModelDesc(C.Structure):
+    """Mirror of si_model_desc (include/si_hip.h)."""
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("intermediate_size", C.c_int32),
+        ("num_conv", C.c_int32),
+        ("conv_dim", C.c_int32 * SI_MAX_CONV), ("conv_kernel", C.c_int32 * SI_MAX_CONV), ("conv_stride", C.c_int32 * SI_MAX_CONV),
+        ("conv_bias", C.c_int32), ("feat_norm_layer", C.c_int32), ("stable_layer_norm", C.c_int32),
+        ("pos_conv_kernel", C.c_int32), ("pos_conv_groups", C.c_int32), ("feat_proj_layer_norm", C.c_int32),
+        ("layer_norm_eps", C.c_float), ("codebook_dim", C.c_int32), ("num_clusters", C.c_int32),
+        ("num_mels", C.c_int32), ("num_ups", C.c_int32),
+        ("up_rates", C.c_int32 * SI_MAX_UPS), ("up_kernels", C.c_int32 * SI_MAX_UPS), ("up_initial_channel", C.c_int32),
+        ("num_rb", C.c_int32), ("rb_kernels", C.c_int32 * SI_MAX_RB), ("num_dil", C.c_int32),
+        ("rb_dilations", (C.c_int32 * SI_MAX_DIL) * SI_MAX_RB),
+        ("encoder_math", C.c_int32), ("vocoder_math", C.c_int32), ("vocoder_chunk", C.c_int32),
+    ]
+
+
+def make_desc(harch: HubertArch, varch: VocoderArch, num_clusters: int, encoder_math: str = "fp32",
+              vocoder_math: str = "fp32", vocoder_chunk: int = 0) -> ModelDesc:
+    d = ModelDesc()
+    d.struct_size = C.sizeof(ModelDesc)
+    d.hidden_size, d.num_layers = harch.hidden_size, harch.num_hidden_layers
+    d.num_heads, d.intermediate_size = harch.num_attention_heads, harch.intermediate_size
+    n = len(harch.conv_dim)
+    if n > SI_MAX_CONV or not (len(harch.conv_kernel) == len(harch.conv_stride) == n):
+        raise ValueError("unsupported conv stack")
+    d.num_conv = n
+    for i in range(n):
+        d.conv_dim[i], d.conv_kernel[i], d.conv_stride[i] = harch.conv_dim[i], harch.conv_kernel[i], harch.conv_stride[i]
+    d.conv_bias = int(harch.conv_bias)
+    if harch.feat_extract_norm not in ("group", "layer"):
+        raise ValueError(f"feat_extract_norm={harch.feat_extract_norm!r}")
+    d.feat_norm_layer = int(harch.feat_extract_norm == "layer")
+    d.stable_layer_norm = int(harch.do_stable_layer_norm)
+    d.pos_conv_kernel, d.pos_conv_groups = harch.num_conv_pos_embeddings, harch.num_conv_pos_embedding_groups
+    d.feat_proj_layer_norm = int(harch.feat_proj_layer_norm)
+    d.layer_norm_eps = harch.layer_norm_eps
+    d.codebook_dim, d.num_clusters = harch.codebook_dim, int(num_clusters)
+    d.num_mels = varch.num_mels
+    nu = len(varch.upsample_rates)
+    if nu > SI_MAX_UPS or len(varch.upsample_kernel_sizes) != nu:
+        raise ValueError("unsupported upsample stack")
+    d.num_ups = nu
+    for i in range(nu):
+        d.up_rates[i], d.up_kernels[i] = varch.upsample_rates[i], varch.upsample_kernel_sizes[i]
+    d.up_initial_channel = varch.upsample_initial_channel
+    nr = len(varch.resblock_kernel_sizes)
+    nd = len(varch.resblock_dilation_sizes[0])
+    if nr > SI_MAX_RB or nd > SI_MAX_DIL or any(len(x) != nd for x in varch.resblock_dilation_sizes):
+        raise ValueError("unsupported resblock shape")
+    d.num_rb, d.num_dil = nr, nd
+    for j in range(nr):
+        d.rb_kernels[j] = varch.resblock_kernel_sizes[j]
+        for k in range(nd):
+            d.rb_dilations[j][k] = varch.resblock_dilation_sizes[j][k]
+    d.encoder_math, d.vocoder_math = SI_MATH[encoder_math], SI_MATH[vocoder_math]
+    d.vocoder_chunk = int(vocoder_chunk)
+    return d
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libsi_hip.so and declare the prototypes.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} is missing: the HIP library has not been built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C speech_inpainting_amd/csrc`).  There is no CPU fallback for the inpainting path.")
+    lib = C.CDLL(p)
+    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    lib.si_version.restype = i32
+    lib.si_create.argtypes = [C.POINTER(vp), i32, C.POINTER(ModelDesc)]
+    lib.si_destroy.argtypes = [vp]
+    lib.si_destroy.restype = None
+    lib.si_last_error.argtypes = [vp]
+    lib.si_last_error.restype = C.c_char_p
+    lib.si_load_weights.argtypes = [vp, vp, sz, C.c_char_p]
+    lib.si_alloc_weights.argtypes = [vp]
+    lib.si_weights_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    lib.si_workspace_bytes.argtypes = [vp, i32, i32, i32, C.POINTER(sz)]
+    lib.si_hubert_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
+    lib.si_codebook_splice.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp]
+    lib.si_hifigan_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, sz, vp]
+    lib.si_num_frames.argtypes = [vp, i32]
+    lib.si_vocoder_samples.argtypes = [vp, i32, i32]
+    lib.si_debug_capture.argtypes = [vp, C.c_char_p, vp, C.c_long]
+    lib.si_debug_size.argtypes = [vp, C.c_char_p]
+    lib.si_debug_size.restype = C.c_long
+    lib.si_profile_start.argtypes = [vp, i32]
+    lib.si_profile_stop.argtypes = [vp, C.POINTER(ProfileEntry), i32, C.POINTER(i32)]
+    for name in EXPORTS:
+        if name not in ("si_destroy", "si_last_error", "si_debug_size"):
+            getattr(lib, name).restype = i32
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class NativeContext:
+    """One si_ctx: a model pair bound to one GPU."""
+
+    def __init__(self, desc: ModelDesc, device: torch.device):
+        self.lib = load_library()
+        if device.type != "cuda":
+            raise RuntimeError(f"the HIP path needs a GPU device, got {device} (no CPU fallback)")
+        self.device = device
+        self.desc = desc
+        self._h = C.c_void_p(0)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        rc = self.lib.si_create(C.byref(self._h), idx, C.byref(desc))
+        if rc != 0:
+            raise NativeError(f"si_create failed ({rc}): {self.lib.si_last_error(None).decode()}")
+        self._ws: Optional[torch.Tensor] = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.si_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise NativeError(f"{what} failed ({rc}): {self.lib.si_last_error(self._h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- weights
+    def load_weights(self, blob: np.ndarray, index: str):
+        blob = np.ascontiguousarray(blob)
+        self._check(self.lib.si_load_weights(self._h, blob.ctypes.data_as(C.c_void_p), blob.nbytes, index.encode()),
+                    "si_load_weights")
+
+    def alloc_weights(self):
+        self._check(self.lib.si_alloc_weights(self._h), "si_alloc_weights")
+
+    def weights_tensor(self) -> torch.Tensor:
+        """The packed device blob as a uint8 tensor view (for the RCCL broadcast)."""
+        p, n = C.c_void_p(0), C.c_size_t(0)
+        self._check(self.lib.si_weights_device_ptr(self._h, C.byref(p), C.byref(n)), "si_weights_device_ptr")
+
+        class _Holder:
+            pass
+        h = _Holder()
+        h.__cuda_array_interface__ = {"shape": (n.value,), "typestr": "|u1", "data": (p.value, False), "version": 2}
+        self._wholder = h
+        return torch.as_tensor(h, device=self.device)
+
+    # ---- shapes / workspace
+    def num_frames(self, n: int) -> int:
+        return int(self.lib.si_num_frames(self._h, n))
+
+    def vocoder_samples(self, tm: int, stretch: bool = True) -> int:
+        return int(self.lib.si_vocoder_samples(self._h, tm, int(stretch)))
+
+    def workspace(self, B: int, N: int, Tm: int) -> torch.Tensor:
+        need = C.c_size_t(0)
+        self._check(self.lib.si_workspace_bytes(self._h, B, N, Tm, C.byref(need)), "si_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ---- forward calls (all enqueue on torch's current stream)
+    def hubert_forward(self, wav: torch.Tensor, mask_start: Optional[torch.Tensor], mask_len: Optional[torch.Tensor],
+                       normalize: bool = True) -> torch.Tensor:
+        assert wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2 and wav.is_contiguous()
+        B, N = wav.shape
+        T = self.num_frames(N)
+        if T < 1:
+            raise ValueError(f"clip of {N} samples is too short")
+        for m in (mask_start, mask_len):
+            assert m is None or (m.is_cuda and m.dtype == torch.int32 and m.numel() == B and m.is_contiguous())
+        out = torch.empty(B, T, self.desc.codebook_dim, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, N, 0)
+        self._check(self.lib.si_hubert_forward(self._h, _ptr(wav), _ptr(mask_start), _ptr(mask_len), int(normalize), B, N,
+                                               _ptr(out), _ptr(ws), ws.numel(), self._stream()), "si_hubert_forward")
+        return out
+
+    def codebook_splice(self, feats: torch.Tensor, frame_pos: torch.Tensor, lm: int, mel: torch.Tensor) -> torch.Tensor:
+        """In-place splice into `mel` (B, D, Tm); returns labels (B, Lm) int64."""
+        assert feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous() and feats.dim() == 3
+        assert mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous() and mel.dim() == 3
+        assert frame_pos.is_cuda and frame_pos.dtype == torch.int32 and frame_pos.is_contiguous()
+        B, T, D = feats.shape
+        assert mel.shape[0] == B and mel.shape[1] == D and frame_pos.numel() == B
+        labels = torch.empty(B, lm, dtype=torch.int64, device=self.device)
+        self._check(self.lib.si_codebook_splice(self._h, _ptr(feats), B, T, _ptr(frame_pos), lm, _ptr(mel), mel.shape[2],
+                                                _ptr(labels), self._stream()), "si_codebook_splice")
+        return labels
+
+    def hifigan_forward(self, mel: torch.Tensor, stretch: bool = True) -> torch.Tensor:
+        assert mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous() and mel.dim() == 3
+        B, D, Tm = mel.shape
+        assert D == self.desc.num_mels
+        L = self.vocoder_samples(Tm, stretch)
+        out = torch.empty(B, L, dtype=torch.float32, device=self.device)
+        need = C.c_size_t(0)
+        self._check(self.lib.si_workspace_bytes(self._h, B, 0, Tm, C.byref(need)), "si_workspace_bytes")
+        ws = self.workspace(B, 0, Tm)
+        self._check(self.lib.si_hifigan_forward(self._h, _ptr(mel), B, Tm, int(stretch), _ptr(out), _ptr(ws), ws.numel(),
+                                                self._stream()), "si_hifigan_forward")
+        return out
+
+    def capture(self, names, capacity: int = 0):
+        """Register capture buffers for the named intermediates (sizes come from the previous forward unless
+        `capacity` floats is given).  Returns {name: tensor}; the tensors are filled by the next forward."""
+        out = {}
+        for nm in names:
+            n = capacity or self.lib.si_debug_size(self._h, nm.encode())
+            if n < 0:
+                raise NativeError(self.lib.si_last_error(self._h).decode())
+            t = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self._check(self.lib.si_debug_capture(self._h, nm.encode(), _ptr(t), n), "si_debug_capture")
+            out[nm] = t
+        self._captures = out
+        return out
+
+    def clear_captures(self):
+        for nm in list(getattr(self, "_captures", {})):
+            self.lib.si_debug_capture(self._h, nm.encode(), C.c_void_p(0), 0)
+        self._captures = {}
+
+    # ---- per-kernel HIP-event timing
+    def profile_start(self, max_launches: int = 20000):
+        self._check(self.lib.si_profile_start(self._h, int(max_launches)), "si_profile_start")
+
+    def profile_stop(self):
+        """-> list of dicts {name, launches, ms, flops, bytes}; waits for the recorded events."""
+        cap = 128
+        arr = (ProfileEntry * cap)()
+        n = C.c_int(0)
+        self._check(self.lib.si_profile_stop(self._h, arr, cap, C.byref(n)), "si_profile_stop")
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops,
+                     bytes=arr[i].bytes) for i in range(min(n.value, cap))]

@@ -119,7 +119,7 @@ def main():
     torch.cuda.synchronize()
     events = not a.no_kernel_events
     if events:
-        eng.ctx.profile_start(600 * max(a.steps, 1))
+        eng.ctx.profile_start(1200 * max(a.steps, 1))
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -1,0 +1,109 @@
+"""`predict.py` entry point of the I_ea path, re-stated over the HIP engine.
+
+Run as the reference is run (I_ea/predict.py:58-62): from a directory holding `predict.yaml`
+
+    python -m speech_inpainting_amd.predict            # or: python predict.py
+
+It reads the reference's YAML schema, loads the same three artefacts (CustomModel `.pt` / local HF directory, HiFi-GAN
+`generator` checkpoint + `config.json`, joblib k-means codebook), and writes the reference's output files
+`<save_pred>/<wave_name>/{orig,masked,hifi_masked,expected_inpaint,inpainted}.wav` (I_ea/predict.py:84,128,134,201,207;
+`expected_inpaint.wav` only when the ground-truth label file exists).  `predict_clips` is the importable batch form.
+
+Differences from the script, all outside the three replaced subsystems: no Whisper `Metrics` object is built (the
+script constructs it and never uses it, I_ea/predict.py:72-73), PNG plots are skipped, and audio loading / resampling
+uses scipy instead of librosa (see audio.py).
+"""
+from __future__ import annotations
+
+import os
+import sys
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import audio
+from .arch import HubertArch, VocoderArch
+from .checkpoint import arch_for_type, load_codebook, load_generator_checkpoint, load_hubert_checkpoint
+from .config import PredictConfig, choose_device, load_predict_config
+from .engine import InpaintingEngine
+
+
+def build_engine(cfg: PredictConfig, device: Optional[torch.device] = None, encoder_dtype: str = "fp32",
+                 vocoder_dtype: str = "fp32") -> InpaintingEngine:
+    device = device or choose_device(cfg.device_index)
+    if device.type != "cuda":
+        raise RuntimeError("no GPU selected/available: this package has no CPU path (device.index in the YAML)")
+    hsd, harch = load_hubert_checkpoint(cfg.hubert_checkpoint, cfg.hubert_type)
+    harch = harch or arch_for_type(cfg.hubert_type)
+    gsd, varch = load_generator_checkpoint(cfg.hifigan_checkpoint)
+    cb = load_codebook(cfg.km_model_path)
+    if cb.shape[0] != cfg.n_clusters:
+        raise ValueError(f"{cfg.km_model_path}: {cb.shape[0]} centroids but km_model.n_clusters = {cfg.n_clusters}")
+    eng = InpaintingEngine(harch, varch, cfg.n_clusters, device, encoder_dtype, vocoder_dtype)
+    return eng.load_state(hsd, gsd, cb)
+
+
+def predict_clips(engine: InpaintingEngine, waves16: Sequence[np.ndarray], waves22: Sequence[np.ndarray],
+                  mask_pos: Sequence[int], mask_frames: int, blind: bool = False) -> Dict[str, torch.Tensor]:
+    """Batch form of I_ea/predict.py:97-207 for clips of EQUAL length.
+    waves16 / waves22: the same clips at 16 kHz / 22.05 kHz (float32, un-normalised), mask_pos: first masked 20 ms frame."""
+    dev = engine.device
+    n16, n22 = len(waves16[0]), len(waves22[0])
+    if any(len(w) != n16 for w in waves16) or any(len(w) != n22 for w in waves22):
+        raise ValueError("clips in one batch must have equal length (group by exact length; HuBERT-base's GroupNorm "
+                         "is not padding-invariant)")
+    masked22 = []
+    for w, p in zip(waves22, mask_pos):
+        m = np.array(w, dtype=np.float32, copy=True)
+        if not blind:
+            s16, e16 = p * 320, (p + mask_frames) * 320
+            m[s16 * 22050 // 16000: e16 * 22050 // 16000] = 0                      # predict.py:99-103
+        masked22.append(audio.peak_normalize(m))                                   # predict.py:104
+    mel = audio.mel_spectrogram(torch.from_numpy(np.stack(masked22)).to(dev)).contiguous()
+    wave = torch.from_numpy(np.stack([np.asarray(w, dtype=np.float32) for w in waves16])).to(dev)
+    pos = torch.tensor(list(mask_pos), dtype=torch.int32, device=dev)
+    out = engine.predict_batch(wave, mel, pos, mask_frames, blind=blind)
+    out["mel_masked"] = mel
+    return out
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    cfg = load_predict_config(argv[0] if argv else "predict.yaml")
+    device = choose_device(cfg.device_index)
+    print("Current device:", device)
+    engine = build_engine(cfg, device)
+    wave_name = cfg.wave_path.split("/")[-1].split(".")[0]
+    save_dir = os.path.join(cfg.save_pred, wave_name)
+    os.makedirs(save_dir, exist_ok=True)
+    wave_22 = audio.load_audio(cfg.wave_path, 22050)
+    wave_16 = audio.load_audio(cfg.wave_path, 16000)
+    audio.write_wav(os.path.join(save_dir, "orig.wav"), wave_16, 16000)
+    pos, lm = cfg.mask_pos, cfg.mask_frames
+    masked_16 = wave_16.copy()
+    masked_16[pos * 320 + 80:(pos + lm) * 320 + 79 - 80] = 0                       # predict.py:133
+    audio.write_wav(os.path.join(save_dir, "masked.wav"), masked_16, 16000)
+
+    out = predict_clips(engine, [wave_16], [wave_22], [pos], lm)
+    # hifi_masked.wav: the vocoder on the masked mel alone (predict.py:123-128)
+    hm = engine.vocode(out["mel_masked"], stretch=True)
+    audio.write_wav(os.path.join(save_dir, "hifi_masked.wav"), audio.to_int16_pcm(hm[0]), 22050)
+    labels_path = os.path.join(cfg.path2centroids, wave_name + "_labels.pt")
+    if os.path.exists(labels_path):                                                # predict.py:160-161,177-189,198-201
+        from .checkpoint import load_codebook as _cb
+        labels = torch.load(labels_path, map_location="cpu").t().reshape(-1)[pos:pos + lm].long()
+        cb = _cb(cfg.km_model_path)
+        exp = out["mel_masked"].clone()
+        exp[0, :, pos:pos + lm] = cb[labels].T.to(exp.device)
+        ew = engine.vocode(exp, stretch=True)
+        audio.write_wav(os.path.join(save_dir, "expected_inpaint.wav"), audio.to_int16_pcm(ew[0]), 22050)
+        print("Target codewords: ", labels.tolist())
+    print("Predicted codewords: ", out["labels"][0].tolist())
+    audio.write_wav(os.path.join(save_dir, "inpainted.wav"), audio.to_int16_pcm(out["wave"][0]), 22050)
+    print("wrote", save_dir)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

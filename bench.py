@@ -6,9 +6,14 @@
 A "step" is one pass of the hot path over one resident batch of synthetic clips: masked 16 kHz waveforms ->
 HuBERT-base encoder -> LN+Linear head -> codeword arg-max + mel splice -> x441/256 stretch -> HiFi-GAN V1 ->
 waveforms.  Workload at every N: BASELINE.json configs[1] per GPU (batch 32 x 4 s clips, 200 ms mask, HuBERT-base
-encoder GEMMs on bf16 MFMA with fp32 accumulate, fp32 vocoder); at N > 1 utterances are sharded, 32 per rank
-(configs[2] at N = 8), weights arrive by one RCCL broadcast, metrics by one all-gather.  Inputs and weights are in HBM
-before the timed region; outputs stay in HBM.
+encoder GEMMs on bf16 MFMA with fp32 accumulate); at N > 1 utterances are sharded, 32 per rank (configs[2] at N = 8),
+weights arrive by one RCCL broadcast, metrics by one all-gather.  Inputs and weights are in HBM before the timed
+region; outputs stay in HBM.
+
+Arithmetic of the headline number: encoder bf16 MFMA (what configs[1] names); vocoder "bf16x3" = every fp32 operand
+split into bf16 hi + lo and each product issued as three bf16 MFMAs (hi*hi + lo*hi + hi*lo, fp32 accumulate), which
+reproduces the fp32 reference waveform to 1.5e-6 RMS (gate 1e-3) -- fp32-equivalent, not reduced precision.  A second,
+shorter leg times the exact-fp32-MFMA vocoder and is reported under "fp32_vocoder".
 
 Prints ONE JSON line on rank 0 (metric/value/... plus `roofline` for the dominant kernel family, measured with HIP
 events inside the timed region, and `cpu_baseline`: the CPU oracle timed on this host's cores on a bounded sample).
@@ -28,8 +33,9 @@ import torch  # noqa: E402
 CLIP_SECONDS = 4.0
 N_SAMPLES = 64000
 MASK_FRAMES = 10          # 200 ms
+GFLOP_PER_CLIP = 268.3    # algorithmic, BASELINE.md section 2
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks
-PEAK_HBM_GBS = 8000.0
+MFMA_PER_PRODUCT = {"f32": 1, "bf16": 1, "bf16x3": 3}
 
 
 def log(*a):
@@ -59,8 +65,27 @@ def cpu_baseline(batch: int):
     t0 = time.perf_counter()
     R.predict_batch(hsd, harch, gsd, varch, cb, wave, mel, pos, MASK_FRAMES)
     dt = time.perf_counter() - t0
-    return {"value": batch * CLIP_SECONDS / dt, "unit": "x real-time (audio-sec/wall-sec)", "cores": cores, "kind": "port",
+    return {"value": round(batch * CLIP_SECONDS / dt, 3), "unit": "x real-time (audio-sec/wall-sec)", "cores": cores, "kind": "port",
             "sample": f"{batch} of the same 4 s clips, one pass, fp32, torch CPU oracle (oracle/ref_cpu.py), {dt:.2f} s wall"}
+
+
+def roofline_of(prof, steps):
+    prof = sorted(prof, key=lambda e: -e["ms"])
+    tot = sum(e["ms"] for e in prof)
+    d = prof[0]
+    m = family_math(d["name"])
+    avg_ms = d["ms"] / d["launches"]
+    ach = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": d["name"], "achieved": round(ach, 2), "peak": PEAK_TFLOPS[m], "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_TFLOPS[m], 4), "traffic": None,
+            "avg_launch_ms": round(avg_ms, 4), "launches_per_step": round(d["launches"] / steps, 1),
+            "share_of_kernel_time": round(d["ms"] / tot, 3), "flops_per_launch": d["flops"] / d["launches"],
+            "mfma_issued_per_product": MFMA_PER_PRODUCT[m],
+            "frac_of_mfma_issue_peak": round(ach * MFMA_PER_PRODUCT[m] / PEAK_TFLOPS[m], 4)}
+    fams = [{"name": e["name"], "ms_per_step": round(e["ms"] / steps, 3),
+             "tflops": round(e["flops"] / e["ms"] / 1e9, 2) if e["ms"] else 0.0,
+             "gbs": round(e["bytes"] / e["ms"] / 1e6, 1) if e["ms"] else 0.0} for e in prof[:8]]
+    return roof, fams, tot
 
 
 def main():
@@ -70,10 +95,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--encoder-dtype", default="bf16", choices=["fp32", "bf16", "bf16x3"])
-    ap.add_argument("--vocoder-dtype", default="fp32", choices=["fp32", "bf16", "bf16x3"])
+    ap.add_argument("--vocoder-dtype", default="bf16x3", choices=["fp32", "bf16", "bf16x3"])
     ap.add_argument("--vocoder-chunk", type=int, default=0)
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the secondary exact-fp32-vocoder leg")
     a = ap.parse_args()
 
     from speech_inpainting_amd import parallel, synth
@@ -82,10 +108,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    rank, local_rank, world = parallel.init_distributed("nccl")
+    rank, local_rank, world = parallel.init_distributed(os.environ.get("SI_DIST_BACKEND", "nccl"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank if local_rank < torch.cuda.device_count() else 0)
     torch.cuda.set_device(dev)
 
     harch, varch = HubertArch.base(), VocoderArch.v1()
@@ -93,12 +119,13 @@ def main():
     B = a.batch
     T = harch.num_frames(N_SAMPLES)
     Tm = mel_frames(N_SAMPLES * 22050 // 16000)
+    state = {}
 
-    t_load = time.perf_counter()
-    eng = parallel.setup_engine(
-        lambda: InpaintingEngine(harch, varch, K, dev, a.encoder_dtype, a.vocoder_dtype, a.vocoder_chunk),
-        lambda: (synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook(K)),
-        rank)
+    def checkpoint():
+        if not state:
+            state["sd"] = (synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook(K))
+        return state["sd"]
+
     # this rank's slice of the global utterance list (seeded per global clip index)
     lo, hi = parallel.shard_range(B * world, rank, world)
     wave = synth.synth_wave(hi - lo, N_SAMPLES, synth.DEFAULT_SEED + 3 + lo).to(dev)
@@ -106,76 +133,89 @@ def main():
     pos = synth.synth_mask_frames(hi - lo, T, MASK_FRAMES, synth.DEFAULT_SEED + 5 + lo).to(dev)
     mstart = (pos * 320 + 80).to(torch.int32)
     mlen = torch.full_like(pos, MASK_FRAMES * 320 - 81)
-    torch.cuda.synchronize()
-    if rank == 0:
-        log(f"[bench] setup {time.perf_counter() - t_load:.1f} s; B={B}/GPU x {world} GPU, T={T}, Tm={Tm}, "
-            f"encoder {a.encoder_dtype}, vocoder {a.vocoder_dtype}")
 
-    def step():
-        return eng.predict_batch(wave, mel, pos, MASK_FRAMES, mask_start=mstart, mask_len=mlen)
+    def run_mode(enc, voc, steps, warmup, events):
+        t_load = time.perf_counter()
+        eng = parallel.setup_engine(lambda: InpaintingEngine(harch, varch, K, dev, enc, voc, a.vocoder_chunk), checkpoint, rank)
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"[bench] encoder {enc}, vocoder {voc}: setup {time.perf_counter() - t_load:.1f} s; B={B}/GPU x {world} GPU, T={T}, Tm={Tm}")
 
-    for _ in range(a.warmup):
-        out = step()
-    torch.cuda.synchronize()
+        def step():
+            return eng.predict_batch(wave, mel, pos, MASK_FRAMES, mask_start=mstart, mask_len=mlen)
+
+        for _ in range(warmup):
+            out = step()
+        torch.cuda.synchronize()
+        if events:
+            eng.ctx.profile_start(1200 * max(steps, 1))
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        elapsed = time.perf_counter() - t0
+        prof = eng.ctx.profile_stop() if events else []
+        wav = out["wave"]
+        finite = bool(torch.isfinite(wav).all())
+        stats = parallel.gather_metrics([elapsed, float(hi - lo), float(wav.pow(2).mean().sqrt()), float(finite)], dev).cpu()
+        del eng
+        elapsed_max = float(stats[:, 0].max())
+        clips = float(stats[:, 1].sum())
+        if not bool(stats[:, 3].min()):
+            raise SystemExit("non-finite samples in the output waveform")
+        return dict(elapsed=elapsed_max, clips=clips, rms=float(stats[0, 2]), prof=prof, steps=steps)
+
     events = not a.no_kernel_events
-    if events:
-        eng.ctx.profile_start(1200 * max(a.steps, 1))
-    parallel.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
-    parallel.barrier()
-    elapsed = time.perf_counter() - t0
-    prof = eng.ctx.profile_stop() if events else []
-
-    wav = out["wave"]
-    finite = bool(torch.isfinite(wav).all())
-    stats = parallel.gather_metrics([elapsed, float(hi - lo), float(wav.pow(2).mean().sqrt()), float(finite)], dev).cpu()
+    main_run = run_mode(a.encoder_dtype, a.vocoder_dtype, a.steps, a.warmup, events)
+    fp32_run = None
+    if not a.no_fp32_leg and a.vocoder_dtype != "fp32":
+        fp32_run = run_mode(a.encoder_dtype, "fp32", max(2, a.steps // 3), 1, events)
     if rank != 0:
         return
-    elapsed_max = float(stats[:, 0].max())
-    clips = float(stats[:, 1].sum())
-    if not bool(stats[:, 3].min()):
-        raise SystemExit("non-finite samples in the output waveform")
-    value = clips * a.steps * CLIP_SECONDS / elapsed_max
 
+    def headline(r):
+        return r["clips"] * r["steps"] * CLIP_SECONDS / r["elapsed"]
+
+    dtype_txt = {"fp32": "fp32 (exact fp32 MFMA)", "bf16": "bf16 MFMA, fp32 accumulate",
+                 "bf16x3": "bf16x3 (fp32 operands split hi+lo, 3 bf16 MFMAs per product, fp32 accumulate: fp32-equivalent)"}
+    clips = main_run["clips"]
     res = {
         "metric": "real-time factor (audio-sec/wall-sec), 4 s clips @16 kHz, 200 ms mask",
-        "value": round(value, 2), "unit": "x real-time (audio-sec/wall-sec), whole job",
+        "value": round(headline(main_run), 2), "unit": "x real-time (audio-sec/wall-sec), whole job",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(1e3 * elapsed_max / a.steps, 3),
+        "ms_per_step": round(1e3 * main_run["elapsed"] / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": f"encoder GEMMs {a.encoder_dtype} MFMA (fp32 accumulate; attention, head, arg-max fp32), vocoder {a.vocoder_dtype}",
+        "dtype": f"encoder GEMMs: {dtype_txt[a.encoder_dtype]} (attention, head, arg-max in fp32); vocoder: {dtype_txt[a.vocoder_dtype]}",
         "data": "synthetic (seeded clips, random-init weights of the HuBERT-base + HiFi-GAN V1 architecture)",
         "config": {"workload": "BASELINE configs[1]: batch=32 x 4 s clips per GPU, 200 ms mask, HuBERT-base + HiFi-GAN V1"
                                + ("" if world == 1 else f", utterance-sharded over {world} GPUs (configs[2] at 8)"),
                    "global_batch": int(clips), "clip_samples": N_SAMPLES, "mask_frames": MASK_FRAMES,
-                   "parallelism": f"utterance-sharded x{world}", "output_rms": round(float(stats[0, 2]), 4)},
-        "clips_per_s": round(clips * a.steps / elapsed_max, 2),
-        "gflop_per_clip_algorithmic": 268.3,
-        "achieved_tflops_whole_path": round(268.3e9 * clips * a.steps / elapsed_max / 1e12, 2),
+                   "parallelism": f"utterance-sharded x{world}", "output_rms": round(main_run["rms"], 4)},
+        "clips_per_s": round(clips * a.steps / main_run["elapsed"], 2),
+        "gflop_per_clip_algorithmic": GFLOP_PER_CLIP,
+        "achieved_tflops_whole_path": round(GFLOP_PER_CLIP * 1e9 * clips * a.steps / main_run["elapsed"] / 1e12, 2),
     }
-    if prof:
-        prof.sort(key=lambda e: -e["ms"])
-        tot = sum(e["ms"] for e in prof)
-        log(f"[bench] per-kernel HIP-event time (rank 0, {a.steps} steps): {tot / a.steps:.2f} ms/step in kernels")
-        for e in prof:
-            log(f"    {e['name']:<28} {e['launches'] / a.steps:7.1f} launches/step {e['ms'] / a.steps:9.3f} ms/step "
+
+    def table(r, tag):
+        roof, fams, tot = roofline_of(r["prof"], r["steps"])
+        log(f"[bench] {tag}: per-kernel HIP-event time (rank 0, {r['steps']} steps): {tot / r['steps']:.2f} ms/step in kernels, "
+            f"{1e3 * r['elapsed'] / r['steps']:.2f} ms/step wall")
+        for e in sorted(r["prof"], key=lambda e: -e["ms"]):
+            log(f"    {e['name']:<28} {e['launches'] / r['steps']:7.1f} launches/step {e['ms'] / r['steps']:9.3f} ms/step "
                 f"{e['flops'] / e['ms'] / 1e9 if e['ms'] else 0:8.2f} TFLOP/s {e['bytes'] / e['ms'] / 1e6 if e['ms'] else 0:9.1f} GB/s (algorithmic)")
-        d = prof[0]
-        m = family_math(d["name"])
-        avg_ms = d["ms"] / d["launches"]
-        ach = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
-        res["roofline"] = {"bound": "mfma", "kernel": d["name"], "achieved": round(ach, 2), "peak": PEAK_TFLOPS[m],
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[m], 4), "traffic": None,
-                           "avg_launch_ms": round(avg_ms, 4), "launches_per_step": round(d["launches"] / a.steps, 1),
-                           "share_of_kernel_time": round(d["ms"] / tot, 3),
-                           "flops_per_launch": d["flops"] / d["launches"]}
-        res["kernel_families"] = [{"name": e["name"], "ms_per_step": round(e["ms"] / a.steps, 3),
-                                   "tflops": round(e["flops"] / e["ms"] / 1e9, 2) if e["ms"] else 0.0,
-                                   "gbs": round(e["bytes"] / e["ms"] / 1e6, 1) if e["ms"] else 0.0} for e in prof[:8]]
+        return roof, fams
+
+    if main_run["prof"]:
+        res["roofline"], res["kernel_families"] = table(main_run, f"{a.encoder_dtype}/{a.vocoder_dtype}")
+    if fp32_run is not None:
+        leg = {"value": round(headline(fp32_run), 2), "ms_per_step": round(1e3 * fp32_run["elapsed"] / fp32_run["steps"], 3),
+               "steps": fp32_run["steps"], "dtype": f"encoder {a.encoder_dtype}, vocoder fp32 (exact fp32 MFMA)"}
+        if fp32_run["prof"]:
+            leg["roofline"], leg["kernel_families"] = table(fp32_run, f"{a.encoder_dtype}/fp32")
+        res["fp32_vocoder"] = leg
     if world == 1 and a.cpu_clips > 0:
         try:
             res["cpu_baseline"] = cpu_baseline(a.cpu_clips)

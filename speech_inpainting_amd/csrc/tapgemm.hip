@@ -13,12 +13,19 @@
 // fp32 -> bf16 / bf16 hi+lo conversion happen while staging, the epilogue (bias, GELU, residual, scale,
 // accumulate) on the accumulators.
 //
+// Pipeline: the loop runs over (chunk, tap) iterations.  While iteration `it` issues its MFMAs out of LDS, the
+// global loads of iteration it+1's weight slab (and, at a chunk boundary, of the next activation tile) are
+// already in flight into registers; they are written to LDS after the MFMAs, into the OTHER weight buffer, so
+// there is one workgroup barrier per iteration.  The activation tile is single-buffered for convolutions (its
+// halo makes it large; a chunk boundary costs one extra barrier every `ntaps` iterations) and double-buffered
+// for ntaps == 1 (Linear layers, where every iteration is a chunk boundary).
+//
 // MFMA use (cdna_hip_programming.md section 3):
 //   F32    v_mfma_f32_32x32x2_f32 : lane l supplies A[l&31][k=l>>5], B[k=l>>5][l&31].  The k index is a
 //          dummy, so lane-half h is given the K range [h*BK/2, (h+1)*BK/2) of the chunk: consecutive MFMA
 //          steps then read consecutive floats and one ds_read_b128 feeds four steps.
 //   BF16   v_mfma_f32_32x32x16_bf16: lane supplies 8 consecutive k (16 B) of row l&31, k block l>>5.
-//   BF16X3 same instruction three times (hi*hi + lo*hi + hi*lo) for ~fp32 accuracy at 3/16 of the fp32 cost.
+//   BF16X3 same instruction three times (lo*hi + hi*lo + hi*hi) for ~fp32 accuracy at 3/16 of the fp32 cost.
 // LDS rows are padded by 16 B so the 16 rows a ds_read_b128 lane group touches fall on distinct 4-bank slots.
 #include <cstdio>
 
@@ -43,6 +50,8 @@ template <int MATH> struct LdsElem { typedef float type; static constexpr int PA
 template <> struct LdsElem<SI_MATH_BF16> { typedef unsigned short type; static constexpr int PAD = 8; };
 template <> struct LdsElem<SI_MATH_BF16X3> { typedef unsigned short type; static constexpr int PAD = 8; };
 
+#define TG_MAXA 12      // float4 of the activation tile a thread can hold in flight (rowsA * BK/4 <= 3072)
+
 template <int MATH, int BM, int BN, int WARPS_M, int WARPS_N, int BK>
 __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
     static_assert(WARPS_M * WARPS_N == 4, "4 waves per workgroup");
@@ -52,6 +61,9 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
     typedef typename LdsElem<MATH>::type elem_t;
     constexpr int LD = BK + LdsElem<MATH>::PAD;          // LDS row stride in elements (row = BK*sizeof + 16 B)
     constexpr int PLANES = (MATH == SI_MATH_BF16X3) ? 2 : 1;
+    constexpr int V4 = BK / 4;                           // float4 per activation row
+    constexpr int VB = (MATH == SI_MATH_F32) ? BK / 4 : BK / 8;     // 16-byte vectors per weight row (per plane)
+    constexpr int MAXB = (BN * VB + 255) / 256;          // 16-byte vectors of a weight slab per thread (per plane)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -70,9 +82,13 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
     const int dil_lo = p.dil < 0 ? (p.ntaps - 1) * p.dil : 0;
     const int base_in = m0 * p.stride - p.pad + dil_lo;          // input row held in LDS row 0
     const int rowsA = (BM - 1) * p.stride + (p.ntaps - 1) * adil + 1;
+    const int nA = rowsA * V4;                                    // float4 in one activation tile
+    const int abufs = p.ntaps == 1 ? 2 : 1;
 
-    elem_t* As = reinterpret_cast<elem_t*>(smem);                 // [PLANES][rowsA][LD]
-    elem_t* Bs = As + (size_t)PLANES * rowsA * LD;                // [PLANES][BN][LD]
+    const size_t a_tile = (size_t)PLANES * rowsA * LD;            // elements per activation buffer
+    constexpr size_t b_tile = (size_t)PLANES * BN * LD;           // elements per weight buffer
+    elem_t* As = reinterpret_cast<elem_t*>(smem);                 // [abufs][PLANES][rowsA][LD]
+    elem_t* Bs = As + (size_t)abufs * a_tile;                     // [2][PLANES][BN][LD]
 
     const float* xs = p.x + (long)seg * p.x_seg_stride + (long)g * p.Cin;
     const size_t wplane = (size_t)p.ntaps * p.Npad * p.Cin;      // elements per group
@@ -86,145 +102,223 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    for (int c0 = 0; c0 < p.Cin; c0 += BK) {
-        __syncthreads();                                          // everyone is done reading As / Bs
-        // ---- stage the halo'd activation tile (all taps read it) ----
-        constexpr int V4 = BK / 4;
-        for (int idx = tid; idx < rowsA * V4; idx += 256) {
-            const int r = idx / V4, j = idx - r * V4;
-            const int grow = base_in + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (grow >= 0 && grow < p.Lin) v = *reinterpret_cast<const f32x4*>(xs + (long)grow * p.ldx + c0 + 4 * j);
+    f32x4 ra[TG_MAXA];                    // activation tile in flight
+    f32x4 rb[PLANES][MAXB];               // weight slab in flight (16 bytes each, whatever the element type)
+
+    auto issueA = [&](int c0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
-            if constexpr (MATH == SI_MATH_F32) {
-                *reinterpret_cast<f32x4*>(As + r * LD + 4 * j) = v;
-            } else {
-                u16x4 hi;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hi[e] = f2bf_rne(v[e]);
-                *reinterpret_cast<u16x4*>(As + r * LD + 4 * j) = hi;
-                if constexpr (MATH == SI_MATH_BF16X3) {
-                    u16x4 lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) lo[e] = f2bf_rne(v[e] - bf2f(hi[e]));
-                    *reinterpret_cast<u16x4*>(As + (size_t)rowsA * LD + r * LD + 4 * j) = lo;
-                }
+        for (int i = 0; i < TG_MAXA; ++i) {
+            const int idx = tid + i * 256;
+            ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < nA) {
+                const int r = idx / V4, j = idx - r * V4;
+                const int grow = base_in + r;
+                if (grow >= 0 && grow < p.Lin) ra[i] = *reinterpret_cast<const f32x4*>(xs + (long)grow * p.ldx + c0 + 4 * j);
             }
         }
-        for (int tap = 0; tap < p.ntaps; ++tap) {
-            if (tap > 0) __syncthreads();                         // previous tap's MFMAs are done with Bs
-            // ---- stage this tap's weight slab W[g][tap][n0 .. n0+BN)[c0 .. c0+BK) ----
-            if constexpr (MATH == SI_MATH_F32) {
-                const float* wg = reinterpret_cast<const float*>(p.w) + (size_t)g * wplane +
-                                  ((size_t)tap * p.Npad + n0) * p.Cin + c0;
-                for (int idx = tid; idx < BN * V4; idx += 256) {
-                    const int r = idx / V4, j = idx - r * V4;
-                    *reinterpret_cast<f32x4*>(Bs + r * LD + 4 * j) =
-                        *reinterpret_cast<const f32x4*>(wg + (size_t)r * p.Cin + 4 * j);
-                }
-            } else {
-                constexpr int V8 = BK / 8;
+    };
+    auto storeA = [&](elem_t* dst) {
 #pragma unroll
-                for (int pl = 0; pl < PLANES; ++pl) {
-                    const unsigned short* wg = reinterpret_cast<const unsigned short*>(pl == 0 ? p.w : p.w_lo) +
-                                               (size_t)g * wplane + ((size_t)tap * p.Npad + n0) * p.Cin + c0;
-                    for (int idx = tid; idx < BN * V8; idx += 256) {
-                        const int r = idx / V8, j = idx - r * V8;
-                        *reinterpret_cast<u16x8*>(Bs + (size_t)pl * BN * LD + r * LD + 8 * j) =
-                            *reinterpret_cast<const u16x8*>(wg + (size_t)r * p.Cin + 8 * j);
+        for (int i = 0; i < TG_MAXA; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < nA) {
+                const int r = idx / V4, j = idx - r * V4;
+                f32x4 v = ra[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+                if constexpr (MATH == SI_MATH_F32) {
+                    *reinterpret_cast<f32x4*>(dst + r * LD + 4 * j) = v;
+                } else {
+                    u16x4 hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hi[e] = f2bf_rne(v[e]);
+                    *reinterpret_cast<u16x4*>(dst + r * LD + 4 * j) = hi;
+                    if constexpr (MATH == SI_MATH_BF16X3) {
+                        u16x4 lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) lo[e] = f2bf_rne(v[e] - bf2f(hi[e]));
+                        *reinterpret_cast<u16x4*>(dst + (size_t)rowsA * LD + r * LD + 4 * j) = lo;
                     }
                 }
             }
-            __syncthreads();
-            // ---- MFMA over this (chunk, tap) ----
-            const int toff = tap * p.dil - dil_lo;               // LDS row offset of this tap (>= 0)
-            if constexpr (MATH == SI_MATH_F32) {
-                const float* ap[TM];
-                const float* bp[TN];
+        }
+    };
+    auto issueB = [&](int c0, int tap) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) ap[i] = As + ((wm0 + i * 32 + l31) * p.stride + toff) * LD + half * (BK / 2);
+        for (int pl = 0; pl < PLANES; ++pl) {
+            const char* wbase = reinterpret_cast<const char*>(pl == 0 ? p.w : p.w_lo) +
+                                sizeof(elem_t) * ((size_t)g * wplane + ((size_t)tap * p.Npad + n0) * p.Cin + c0);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bp[j] = Bs + (wn0 + j * 32 + l31) * LD + half * (BK / 2);
-#pragma unroll
-                for (int s4 = 0; s4 < BK / 8; ++s4) {
-                    f32x4 a[TM], b[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap[i] + 4 * s4);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bp[j] + 4 * s4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < MAXB; ++i) {
+                const int idx = tid + i * 256;
+                if (BN * VB % 256 == 0 || idx < BN * VB) {
+                    const int r = idx / VB, j = idx - r * VB;
+                    rb[pl][i] = *reinterpret_cast<const f32x4*>(wbase + sizeof(elem_t) * (size_t)r * p.Cin + 16 * j);
                 }
-            } else {
-                const unsigned short* ap[TM];
-                const unsigned short* bp[TN];
+            }
+        }
+    };
+    auto storeB = [&](elem_t* dst) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) ap[i] = As + ((wm0 + i * 32 + l31) * p.stride + toff) * LD + half * 8;
+        for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bp[j] = Bs + (wn0 + j * 32 + l31) * LD + half * 8;
+            for (int i = 0; i < MAXB; ++i) {
+                const int idx = tid + i * 256;
+                if (BN * VB % 256 == 0 || idx < BN * VB) {
+                    const int r = idx / VB, j = idx - r * VB;
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(dst + (size_t)pl * BN * LD + r * LD) + 16 * j) = rb[pl][i];
+                }
+            }
+    };
+
+    const int nchunks = p.Cin / BK;
+    const int total = nchunks * p.ntaps;
+
+    // (Measured and rejected: delaying the second resident workgroup of each CU by 1/2 or 1 tile to break the
+    // lock-step of co-resident workgroups cost 3-5 % on every fp32 shape.)
+    issueA(0);
+    issueB(0, 0);
+    storeA(As);
+    storeB(Bs);
+    __syncthreads();
+
+    int chunk = 0, tap = 0;
+    for (int it = 0; it < total; ++it) {
+        const bool has_next = it + 1 < total;
+        const bool new_chunk = has_next && (tap == p.ntaps - 1);
+        const int ntap = new_chunk ? 0 : tap + 1;
+        const int nchunk = new_chunk ? chunk + 1 : chunk;
+        if (has_next) issueB(nchunk * BK, ntap);
+        if (new_chunk) issueA(nchunk * BK);
+
+        // ---- MFMA over this (chunk, tap) out of LDS ----
+        const elem_t* Ac = As + (size_t)(abufs == 2 ? (chunk & 1) : 0) * a_tile;
+        const elem_t* Bc = Bs + (size_t)(it & 1) * b_tile;
+        const int toff = tap * p.dil - dil_lo;                   // LDS row offset of this tap (>= 0)
+        if constexpr (MATH == SI_MATH_F32) {
+            const float* ap[TM];
+            const float* bp[TN];
 #pragma unroll
-                for (int ks = 0; ks < BK / 16; ++ks) {
-                    bf16x8 ah[TM], bh[TN];
+            for (int i = 0; i < TM; ++i) ap[i] = Ac + ((wm0 + i * 32 + l31) * p.stride + toff) * LD + half * (BK / 2);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const bf16x8*>(ap[i] + 16 * ks);
+            for (int j = 0; j < TN; ++j) bp[j] = Bc + (wn0 + j * 32 + l31) * LD + half * (BK / 2);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const bf16x8*>(bp[j] + 16 * ks);
-                    if constexpr (MATH == SI_MATH_BF16X3) {
-                        bf16x8 al[TM], bl[TN];
+            for (int s4 = 0; s4 < BK / 8; ++s4) {
+                f32x4 a[TM], b[TN];
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            al[i] = *reinterpret_cast<const bf16x8*>(ap[i] + (size_t)rowsA * LD + 16 * ks);
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap[i] + 4 * s4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bp[j] + 4 * s4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            bl[j] = *reinterpret_cast<const bf16x8*>(bp[j] + (size_t)BN * LD + 16 * ks);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const unsigned short* ap[TM];
+            const unsigned short* bp[TN];
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) ap[i] = Ac + ((wm0 + i * 32 + l31) * p.stride + toff) * LD + half * 8;
 #pragma unroll
-                            for (int j = 0; j < TN; ++j) {
-                                // small terms first so they are not swamped by the running sum
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                            }
-                    } else {
+            for (int j = 0; j < TN; ++j) bp[j] = Bc + (wn0 + j * 32 + l31) * LD + half * 8;
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 ah[TM], bh[TN];
 #pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
+                for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const bf16x8*>(ap[i] + 16 * ks);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const bf16x8*>(bp[j] + 16 * ks);
+                if constexpr (MATH == SI_MATH_BF16X3) {
+                    bf16x8 al[TM], bl[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        al[i] = *reinterpret_cast<const bf16x8*>(ap[i] + (size_t)rowsA * LD + 16 * ks);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        bl[j] = *reinterpret_cast<const bf16x8*>(bp[j] + (size_t)BN * LD + 16 * ks);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            // small terms first so they are not swamped by the running sum
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
             }
         }
+
+        // ---- land the prefetched tiles ----
+        if (has_next) {
+            if (new_chunk && abufs == 1) __syncthreads();         // every wave is done reading the activation tile
+            storeB(Bs + (size_t)((it + 1) & 1) * b_tile);
+            if (new_chunk) storeA(As + (size_t)(abufs == 2 ? (nchunk & 1) : 0) * a_tile);
+            __syncthreads();
+        }
+        tap = ntap;
+        chunk = nchunk;
     }
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-    const long obase = (long)seg * p.o_seg_stride;
+    // Residual / accumulate reads are issued as one unconditional batch per 32x32 tile (out-of-range elements
+    // read the segment's element 0 and are dropped at the store): a per-element predicated read serialises 16
+    // dependent global round trips per tile and doubled the time of every residual conv.
+    // Offsets inside a segment are 32-bit (the launcher checks olimit < 2^31) off a workgroup-uniform base.
+    float* const outp = p.out + (long)seg * p.o_seg_stride;
+    const float* const resp = p.res ? p.res + (long)seg * p.o_seg_stride : nullptr;
+    const bool has_res = p.res != nullptr;
+    const bool acc_out = p.accumulate != 0;
+    const bool gelu = p.act == SI_ACT_GELU;
+    const int olim = (int)p.olimit;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn0 + j * 32 + l31;
-            if (n >= p.N) continue;
-            const float bv = p.bias ? p.bias[g * p.N + n] : 0.f;
+            const bool nok = n < p.N;
+            const float bv = (p.bias && nok) ? p.bias[g * p.N + n] : 0.f;
+            const int col = g * p.N + n + (int)p.ooff;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m >= p.M) continue;
-                const long flat = (long)m * p.ldo + (long)g * p.N + n + p.ooff;
-                if (flat < 0 || flat >= p.olimit) continue;
-                float v = acc[i][j][r] + bv;
-                if (p.act == SI_ACT_GELU) v = gelu_erf(v);
-                if (p.res) v += p.res[obase + flat];
-                v *= p.alpha;
-                if (p.accumulate) v += p.out[obase + flat];
-                p.out[obase + flat] = v;
+            for (int hb = 0; hb < 2; ++hb) {                       // two batches of 8 keep the register footprint small
+                int fl[8];
+                unsigned okm = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = hb * 8 + q;
+                    const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const long flat = (long)m * p.ldo + col;
+                    const bool ok = nok && m < p.M && flat >= 0 && flat < olim;
+                    okm |= (ok ? 1u : 0u) << q;
+                    fl[q] = ok ? (int)flat : 0;
+                }
+                float rv[8], ov[8];
+                if (has_res) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rv[q] = resp[fl[q]];
+                }
+                if (acc_out) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) ov[q] = outp[fl[q]];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float v = acc[i][j][hb * 8 + q] + bv;
+                    if (gelu) v = gelu_erf(v);
+                    if (has_res) v += rv[q];
+                    v *= p.alpha;
+                    if (acc_out) v += ov[q];
+                    if ((okm >> q) & 1u) outp[fl[q]] = v;
+                }
             }
         }
     }
@@ -237,7 +331,11 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     constexpr int PLANES = (MATH == SI_MATH_BF16X3) ? 2 : 1;
     const int adil = p.dil < 0 ? -p.dil : p.dil;
     const int rowsA = (BM - 1) * p.stride + (p.ntaps - 1) * adil + 1;
-    const size_t lds = (size_t)PLANES * (rowsA + BN) * LD * sizeof(elem_t);
+    if (rowsA * (BK / 4) > TG_MAXA * 256)
+        return si_fail(ctx, SI_EINVAL, "tapgemm: activation tile of %d rows exceeds the prefetch registers (stride %d, taps %d, dil %d)",
+                       rowsA, p.stride, p.ntaps, p.dil);
+    const int abufs = p.ntaps == 1 ? 2 : 1;
+    const size_t lds = (size_t)PLANES * ((size_t)abufs * rowsA + 2 * BN) * LD * sizeof(elem_t);
     if (lds > 160 * 1024) return si_fail(ctx, SI_EINVAL, "tapgemm: LDS tile of %zu bytes exceeds 160 KiB", lds);
     auto kern = tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK>;
     if (lds > 64 * 1024) {
@@ -262,8 +360,12 @@ template <int MATH, int BK>
 static int launch_math(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     const int bn = si_pick_bn(p.N);
     if (bn == 128) return launch_cfg<MATH, 128, 128, 2, 2, BK>(ctx, p, st);
-    if (bn == 64) return launch_cfg<MATH, 256, 64, 4, 1, BK>(ctx, p, st);
-    return launch_cfg<MATH, 256, 32, 4, 1, BK>(ctx, p, st);
+    // narrow N: 256-row tiles unless their halo'd activation tile would not fit the prefetch registers
+    // (strided convs), or the segment is so short that a 256-row tile would be mostly padding
+    const int adil = p.dil < 0 ? -p.dil : p.dil;
+    const bool tall = ((255 * p.stride + (p.ntaps - 1) * adil + 1) * (BK / 4) <= TG_MAXA * 256) && p.M > 128;
+    if (bn == 64) return tall ? launch_cfg<MATH, 256, 64, 4, 1, BK>(ctx, p, st) : launch_cfg<MATH, 128, 64, 2, 2, BK>(ctx, p, st);
+    return tall ? launch_cfg<MATH, 256, 32, 4, 1, BK>(ctx, p, st) : launch_cfg<MATH, 128, 32, 4, 1, BK>(ctx, p, st);
 }
 
 int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t st) {
@@ -272,6 +374,8 @@ int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t
     if (p.Npad % si_pick_bn(p.N) != 0 || p.Npad < p.N)
         return si_fail(ctx, SI_EINVAL, "tapgemm: Npad=%d does not match N=%d", p.Npad, p.N);
     if (p.M <= 0 || p.nseg <= 0) return SI_OK;
+    if (p.olimit >= (1L << 31) || (long)p.M * p.ldo + p.ooff >= (1L << 31) || (long)p.Lin * p.ldx >= (1L << 31))
+        return si_fail(ctx, SI_EINVAL, "tapgemm: a segment of %ld floats exceeds the 32-bit in-segment offsets", p.olimit);
     const bool k32 = (p.Cin % 32 == 0);
     switch (math) {
         case SI_MATH_F32: return k32 ? launch_math<SI_MATH_F32, 32>(ctx, p, st) : launch_math<SI_MATH_F32, 16>(ctx, p, st);

@@ -94,14 +94,20 @@ def test_bf16_encoder_mode_reports_label_agreement():
         assert rms(out["wave"], z["wave"]) <= 1e-3
 
 
-@pytest.mark.parametrize("voc,tol", [("bf16x3", 1e-4), ("bf16", 2e-2)])
-def test_vocoder_reduced_precision_modes(voc, tol):
-    c = load_case("tiny_group")
+@pytest.mark.parametrize("name,voc,tol", [("tiny_group", "bf16x3", 1e-5), ("base_4s", "bf16x3", 1e-5), ("large_4s", "bf16x3", 1e-5),
+                                          ("base_4s", "bf16", 1e-3)])
+def test_vocoder_split_bf16_modes(name, voc, tol):
+    """bf16x3 (hi/lo split, 3 MFMAs per product) is the benchmark's vocoder arithmetic: it must stay fp32-equivalent
+    (measured 1.5e-6 RMS at full size).  Plain bf16 is only required to meet the north-star gate (measured 7.4e-4)."""
+    c = load_case(name)
     z = c["z"]
     out = _run(_engine(c, voc=voc), c)
     assert np.array_equal(out["labels"].numpy(), z["labels"])
-    err = rms(out["wave"], z["wave"])
-    print(f"vocoder {voc}: waveform rms error {err:.3e}")
+    if "wave" in z.files:
+        err = rms(out["wave"], z["wave"])
+    else:
+        err = max(rms(out["wave"][:, :2048], z["wave_head"]), rms(out["wave"][:, -2048:], z["wave_tail"]))
+    print(f"{name} vocoder {voc}: waveform rms error {err:.3e}")
     assert err <= tol
 
 

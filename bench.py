@@ -108,7 +108,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    rank, local_rank, world = parallel.init_distributed(os.environ.get("SI_DIST_BACKEND", "nccl"))
+    backend = os.environ.get("SI_DIST_BACKEND", "nccl")      # "gloo" only to rehearse N > 1 on a single GPU
+    rank, local_rank, world = parallel.init_distributed(backend)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     dev = torch.device("cuda", local_rank if local_rank < torch.cuda.device_count() else 0)
@@ -160,7 +161,8 @@ def main():
         prof = eng.ctx.profile_stop() if events else []
         wav = out["wave"]
         finite = bool(torch.isfinite(wav).all())
-        stats = parallel.gather_metrics([elapsed, float(hi - lo), float(wav.pow(2).mean().sqrt()), float(finite)], dev).cpu()
+        stats = parallel.gather_metrics([elapsed, float(hi - lo), float(wav.pow(2).mean().sqrt()), float(finite)],
+                                        dev if backend == "nccl" else "cpu").cpu()
         del eng
         elapsed_max = float(stats[:, 0].max())
         clips = float(stats[:, 1].sum())

@@ -345,7 +345,7 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     dim3 grid((unsigned)(p.nseg * mtiles), (unsigned)((p.N + BN - 1) / BN), (unsigned)p.groups);
     static const char* const math_names[] = {"f32", "bf16", "bf16x3"};
     char name[48];
-    snprintf(name, sizeof(name), "tapgemm_%s_%dx%d", math_names[MATH], BM, BN);
+    snprintf(name, sizeof(name), "tapgemm_%s_%dx%d%s", math_names[MATH], BM, BN, BK == 64 ? "k64" : "");
     const double macs = p.algo_macs > 0 ? p.algo_macs : (double)p.nseg * p.M * p.N * p.groups * (double)p.Cin * p.ntaps;
     double bytes = 4.0 * p.nseg * ((double)p.Lin * p.Cin * p.groups + (double)p.M * p.N * p.groups * (1 + (p.res ? 1 : 0) + (p.accumulate ? 1 : 0))) +
                    (double)p.groups * p.ntaps * p.N * p.Cin * (MATH == SI_MATH_F32 ? 4 : (MATH == SI_MATH_BF16 ? 2 : 4));
@@ -377,10 +377,21 @@ int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t
     if (p.olimit >= (1L << 31) || (long)p.M * p.ldo + p.ooff >= (1L << 31) || (long)p.Lin * p.ldx >= (1L << 31))
         return si_fail(ctx, SI_EINVAL, "tapgemm: a segment of %ld floats exceeds the 32-bit in-segment offsets", p.olimit);
     const bool k32 = (p.Cin % 32 == 0);
+    // bf16 MFMAs retire a 32-deep K chunk in a quarter of the fp32 time, so the barrier + staging cost per chunk
+    // dominates; a 64-deep chunk halves it where the (wider) activation tile still fits the prefetch registers.
+    static const int bk64_mode = getenv("SI_TG_BK64") ? atoi(getenv("SI_TG_BK64")) : 0;
+    const int adil = p.dil < 0 ? -p.dil : p.dil;
+    const int bm = si_pick_bn(p.N) == 128 ? 128 : 256;
+    const bool k64 = bk64_mode && math != SI_MATH_F32 && p.Cin % 64 == 0 &&
+                     ((bm - 1) * p.stride + (p.ntaps - 1) * adil + 1) * 16 <= TG_MAXA * 256;
     switch (math) {
         case SI_MATH_F32: return k32 ? launch_math<SI_MATH_F32, 32>(ctx, p, st) : launch_math<SI_MATH_F32, 16>(ctx, p, st);
-        case SI_MATH_BF16: return k32 ? launch_math<SI_MATH_BF16, 32>(ctx, p, st) : launch_math<SI_MATH_BF16, 16>(ctx, p, st);
-        case SI_MATH_BF16X3: return k32 ? launch_math<SI_MATH_BF16X3, 32>(ctx, p, st) : launch_math<SI_MATH_BF16X3, 16>(ctx, p, st);
+        case SI_MATH_BF16:
+            if (k64) return launch_math<SI_MATH_BF16, 64>(ctx, p, st);
+            return k32 ? launch_math<SI_MATH_BF16, 32>(ctx, p, st) : launch_math<SI_MATH_BF16, 16>(ctx, p, st);
+        case SI_MATH_BF16X3:
+            if (k64) return launch_math<SI_MATH_BF16X3, 64>(ctx, p, st);
+            return k32 ? launch_math<SI_MATH_BF16X3, 32>(ctx, p, st) : launch_math<SI_MATH_BF16X3, 16>(ctx, p, st);
     }
     return si_fail(ctx, SI_EINVAL, "tapgemm: unknown math mode %d", math);
 }

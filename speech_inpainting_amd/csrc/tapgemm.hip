@@ -34,6 +34,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
@@ -73,10 +74,14 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
     const int wm0 = (wave / WARPS_N) * WM, wn0 = (wave % WARPS_N) * WN;
 
     const int mtiles = (p.M + BM - 1) / BM;
-    const int seg = blockIdx.x / mtiles;
-    const int m0 = (blockIdx.x % mtiles) * BM;
-    const int n0 = blockIdx.y * BN;
-    const int g = blockIdx.z;
+    // N-tiles of one M-tile are adjacent in dispatch order: they read the same activation rows, so all but the
+    // first find them in L2 / Infinity Cache instead of HBM.
+    const int ntn = (p.N + BN - 1) / BN;
+    const int mt = blockIdx.x / ntn;
+    const int seg = mt / mtiles;
+    const int m0 = (mt % mtiles) * BM;
+    const int n0 = (blockIdx.x % ntn) * BN;
+    const int g = blockIdx.y;
 
     const int adil = p.dil < 0 ? -p.dil : p.dil;
     const int dil_lo = p.dil < 0 ? (p.ntaps - 1) * p.dil : 0;
@@ -129,15 +134,14 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
                 if constexpr (MATH == SI_MATH_F32) {
                     *reinterpret_cast<f32x4*>(dst + r * LD + 4 * j) = v;
                 } else {
-                    u16x4 hi;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) hi[e] = f2bf_rne(v[e]);
-                    *reinterpret_cast<u16x4*>(dst + r * LD + 4 * j) = hi;
+                    // vector casts lower to v_cvt_pk_bf16_f32 (round-to-nearest-even, 2 elements per instruction);
+                    // a bit-twiddled RNE costs ~15 VALU ops per element, which in bf16x3 mode rivalled the MFMA
+                    // time of a whole chunk
+                    const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+                    *reinterpret_cast<bf16x4*>(dst + r * LD + 4 * j) = hi;
                     if constexpr (MATH == SI_MATH_BF16X3) {
-                        u16x4 lo;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) lo[e] = f2bf_rne(v[e] - bf2f(hi[e]));
-                        *reinterpret_cast<u16x4*>(dst + (size_t)rowsA * LD + r * LD + 4 * j) = lo;
+                        const f32x4 rem = v - __builtin_convertvector(hi, f32x4);
+                        *reinterpret_cast<bf16x4*>(dst + (size_t)rowsA * LD + r * LD + 4 * j) = __builtin_convertvector(rem, bf16x4);
                     }
                 }
             }
@@ -342,7 +346,7 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
         SI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const int mtiles = (p.M + BM - 1) / BM;
-    dim3 grid((unsigned)(p.nseg * mtiles), (unsigned)((p.N + BN - 1) / BN), (unsigned)p.groups);
+    dim3 grid((unsigned)(p.nseg * mtiles * ((p.N + BN - 1) / BN)), (unsigned)p.groups);
     static const char* const math_names[] = {"f32", "bf16", "bf16x3"};
     char name[48];
     snprintf(name, sizeof(name), "tapgemm_%s_%dx%d%s", math_names[MATH], BM, BN, BK == 64 ? "k64" : "");

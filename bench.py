@@ -69,6 +69,21 @@ def cpu_baseline(batch: int):
             "sample": f"{batch} of the same 4 s clips, one pass, fp32, torch CPU oracle (oracle/ref_cpu.py), {dt:.2f} s wall"}
 
 
+def measured_traffic(family: str):
+    """HBM bytes per launch of a kernel family from the newest committed PMC table (profiles/rNN_hbm_traffic.json,
+    written by tools/collect_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        tab = json.load(open(files[-1]))
+    except Exception:
+        return None, None
+    e = tab.get(family)
+    return (round(e["hbm_bytes_per_launch"]), os.path.basename(files[-1])) if e else (None, None)
+
+
 def roofline_of(prof, steps):
     prof = sorted(prof, key=lambda e: -e["ms"])
     tot = sum(e["ms"] for e in prof)
@@ -76,8 +91,10 @@ def roofline_of(prof, steps):
     m = family_math(d["name"])
     avg_ms = d["ms"] / d["launches"]
     ach = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+    traffic, tsrc = measured_traffic(d["name"])
     roof = {"bound": "mfma", "kernel": d["name"], "achieved": round(ach, 2), "peak": PEAK_TFLOPS[m], "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_TFLOPS[m], 4), "traffic": None,
+            "frac": round(ach / PEAK_TFLOPS[m], 4), "traffic": traffic, "traffic_source": tsrc,
+            "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
             "avg_launch_ms": round(avg_ms, 4), "launches_per_step": round(d["launches"] / steps, 1),
             "share_of_kernel_time": round(d["ms"] / tot, 3), "flops_per_launch": d["flops"] / d["launches"],
             "mfma_issued_per_product": MFMA_PER_PRODUCT[m],

@@ -1,0 +1,104 @@
+"""The remaining BASELINE.json configs at their own shapes, against the (pinned) CPU oracle and through
+size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from tests.common import rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(harch, varch, enc="fp32", voc="fp32", K=100):
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.engine import InpaintingEngine
+    hsd, gsd, cb = synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook(K)
+    return InpaintingEngine(harch, varch, K, "cuda:0", enc, voc).load_state(hsd, gsd, cb), (hsd, gsd, cb)
+
+
+def test_config5_blind_10s_clip_matches_oracle():
+    """configs[4]: blind inpainting (every frame replaced) on a 10 s clip: T = 499 encoder frames (attention streams
+    16 key tiles), 500 mel frames -> 861 -> 220 416 samples."""
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch, mel_frames
+    harch, varch = HubertArch.base(), VocoderArch.v1()
+    eng, (hsd, gsd, cb) = _mk(harch, varch)
+    N = 160000
+    Tm = mel_frames(N * 22050 // 16000)
+    assert harch.num_frames(N) == 499 and Tm == 500
+    wave, mel = synth.synth_wave(1, N, 21), synth.synth_mel(1, Tm, 80, 22)
+    pos = torch.zeros(1, dtype=torch.int32)
+    out = eng.predict_batch(wave.cuda(), mel.cuda(), pos.cuda(), 0, blind=True)
+    torch.cuda.synchronize()
+    torch.set_num_threads(16)
+    ref = R.predict_batch(hsd, harch, gsd, varch, cb, wave, mel, [0], 0, blind=True)
+    assert out["wave"].shape == (1, 861 * 256) == tuple(ref["wave"].shape)
+    agree = float((out["labels"].cpu() == ref["labels"]).float().mean())
+    err = rms(out["wave"].cpu(), ref["wave"])
+    print(f"10 s blind: label agreement {agree:.3f} over {ref['labels'].numel()} frames, waveform rms error {err:.3e}")
+    assert rms(out["feats"].cpu(), ref["feats"]) <= 1e-4 * rms(ref["feats"])
+    assert agree == 1.0 and err <= 1e-4
+
+
+def test_config4_large_encoder_batch_matches_oracle_per_clip():
+    """configs[3] encoder: HuBERT-large (24 pre-LN layers, LayerNorm feature extractor with bias), 400 ms mask; a batch of
+    3 clips with different mask positions against the oracle run clip by clip."""
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    harch, varch = HubertArch.large(), VocoderArch.tiny()
+    eng, (hsd, gsd, cb) = _mk(harch, varch)
+    B, N, lm = 3, 64000, 20
+    wave = synth.synth_wave(B, N, 31)
+    pos = torch.tensor([10, 90, 170], dtype=torch.int32)
+    sl = [R.mask_samples_from_frames(int(p), lm) for p in pos]
+    ms = torch.tensor([s for s, _ in sl], dtype=torch.int32)
+    ml = torch.tensor([l for _, l in sl], dtype=torch.int32)
+    feats = eng.encode(wave.cuda(), ms.cuda(), ml.cuda()).cpu()
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = R.custom_model_forward(hsd, harch, R.mask_and_normalize(wave, ms.tolist(), ml.tolist()))
+    assert feats.shape == ref.shape == (B, 199, 80)
+    assert rms(feats, ref) <= 1e-4 * rms(ref)
+
+
+def test_full_size_batch_is_clipwise_identical_to_single_clip_runs():
+    """At the bench's own shape (B = 32, base + V1, the bench's arithmetic): every clip of the batch equals that clip run
+    alone, bit for bit, and two runs are identical -- sharding by utterance cannot change results."""
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch, mel_frames
+    harch, varch = HubertArch.base(), VocoderArch.v1()
+    eng, _ = _mk(harch, varch, enc="bf16", voc="bf16x3")
+    B, N, lm = 32, 64000, 10
+    Tm = mel_frames(N * 22050 // 16000)
+    wave, mel = synth.synth_wave(B, N, 41).cuda(), synth.synth_mel(B, Tm, 80, 42).cuda()
+    pos = synth.synth_mask_frames(B, 199, lm, 43).cuda()
+    a = eng.predict_batch(wave, mel, pos, lm)
+    b = eng.predict_batch(wave, mel, pos, lm)
+    assert torch.equal(a["wave"], b["wave"]) and torch.equal(a["labels"], b["labels"])
+    assert a["wave"].shape == (B, 344 * 256) and bool(torch.isfinite(a["wave"]).all())
+    for i in (0, 17, 31):
+        one = eng.predict_batch(wave[i:i + 1].contiguous(), mel[i:i + 1].contiguous(), pos[i:i + 1].contiguous(), lm)
+        assert torch.equal(one["labels"], a["labels"][i:i + 1])
+        assert torch.equal(one["wave"], a["wave"][i:i + 1])
+    # splice property: outside the masked frames the mel is untouched, inside it is a codebook row
+    cb = synth.synth_codebook(100).cuda()
+    for i in (3, 20):
+        p = int(pos[i])
+        assert torch.equal(a["mel"][i, :, :p], mel[i, :, :p]) and torch.equal(a["mel"][i, :, p + lm:], mel[i, :, p + lm:])
+        assert torch.allclose(a["mel"][i, :, p:p + lm].T, cb[a["labels"][i]], atol=1e-6)
+
+
+def test_vocoder_is_shift_consistent():
+    """Domain property of a fully convolutional generator: away from the edges (receptive field ~ 3 mel frames of
+    conv_pre + the MRF halos), delaying the mel by one frame delays the waveform by exactly `hop` samples."""
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    eng, _ = _mk(HubertArch.tiny(), VocoderArch.v1(), voc="bf16x3")
+    mel = synth.synth_mel(1, 120, 80, 51).cuda()
+    shifted = torch.roll(mel, 1, dims=2)
+    a = eng.vocode(mel, stretch=False)[0]
+    b = eng.vocode(shifted, stretch=False)[0]
+    lo, hi = 40 * 256, 80 * 256
+    assert rms(b[lo + 256:hi + 256].cpu(), a[lo:hi].cpu()) <= 1e-5

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md section HBM prescribes)
+into a per-kernel-family HBM-traffic table: profiles/rNN_hbm_traffic.json, which bench.py reads for `roofline.traffic`.
+
+    python tools/collect_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+
+Units and corrections (MI355X_MICROARCH.md): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly
+half of the bytes of a wide coalesced streaming read (16 B/lane), so it is doubled; WRITE_SIZE is exact for 16-B
+streaming stores.  Our epilogue stores are 4 B/lane (128-B segments), which the guide lists as uncalibrated: the
+write figure is therefore reported as-is and flagged.  Values are per launch (mean over the launches of a family).
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+MATH = {"0": "f32", "1": "bf16", "2": "bf16x3"}
+
+
+def family(kernel_name: str) -> str:
+    m = re.search(r"tapgemm_kernel<(\d), (\d+), (\d+), \d, \d, (\d+)>", kernel_name)
+    if m:
+        return f"tapgemm_{MATH[m.group(1)]}_{m.group(2)}x{m.group(3)}" + ("k64" if m.group(4) == "64" else "")
+    return re.sub(r"_kernel.*|\(.*", "", kernel_name).replace("void ", "")
+
+
+def per_family(path, counter):
+    tot, n = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            f = family(r["Kernel_Name"])
+            tot[f] += float(r["Counter_Value"])
+            n[f] += 1
+    return {f: (tot[f] / n[f], n[f]) for f in tot}
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    F, W = per_family(fetch, "FETCH_SIZE"), per_family(write, "WRITE_SIZE")
+    res = {}
+    for f in sorted(set(F) | set(W)):
+        fk, nf = F.get(f, (0.0, 0))
+        wk, nw = W.get(f, (0.0, 0))
+        res[f] = {"launches_sampled": int(max(nf, nw)),
+                  "fetch_bytes_per_launch": 2.0 * fk * 1024.0,          # gfx950: FETCH_SIZE counts half of wide coalesced reads
+                  "write_bytes_per_launch": wk * 1024.0,
+                  "hbm_bytes_per_launch": 2.0 * fk * 1024.0 + wk * 1024.0,
+                  "note": "FETCH_SIZE doubled (gfx950 correction); WRITE_SIZE as reported (4-B/lane stores: uncalibrated width)"}
+    json.dump(res, open(out, "w"), indent=1)
+    for f, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])[:8]:
+        print(f"{f:<28} n={v['launches_sampled']:4d}  fetch {v['fetch_bytes_per_launch'] / 1e6:9.1f} MB  write {v['write_bytes_per_launch'] / 1e6:9.1f} MB per launch")
+
+
+if __name__ == "__main__":
+    main()

@@ -13,12 +13,16 @@
 // fp32 -> bf16 / bf16 hi+lo conversion happen while staging, the epilogue (bias, GELU, residual, scale,
 // accumulate) on the accumulators.
 //
-// Pipeline: the loop runs over (chunk, tap) iterations.  While iteration `it` issues its MFMAs out of LDS, the
-// global loads of iteration it+1's weight slab (and, at a chunk boundary, of the next activation tile) are
-// already in flight into registers; they are written to LDS after the MFMAs, into the OTHER weight buffer, so
-// there is one workgroup barrier per iteration.  The activation tile is single-buffered for convolutions (its
-// halo makes it large; a chunk boundary costs one extra barrier every `ntaps` iterations) and double-buffered
-// for ntaps == 1 (Linear layers, where every iteration is a chunk boundary).
+// Pipeline: the loop runs over (chunk, tap) iterations.  In the bf16 modes an iteration's MFMA work (24 x 32
+// cycles in bf16x3, 8 x 32 in bf16) is SHORTER than the L2 latency of a weight slab, so a slab fetched one
+// iteration ahead stalls every iteration (measured: 32 % MFMA utilisation = two workgroups per CU each retiring
+// one iteration per memory latency).  Weight slabs are therefore prefetched TWO iterations ahead into two
+// register sets; the next activation chunk is issued at the first tap of the current chunk (ntaps-1 iterations
+// ahead), or two chunks ahead in two half-sets for ntaps == 1 (Linear).  Registers are written to the OTHER LDS
+// weight buffer after the MFMAs: one workgroup barrier per iteration (plus one per chunk boundary for
+// convolutions, whose halo'd activation tile is single-buffered to keep two workgroups per CU).
+// All loads are ordinary register loads, so the compiler's counted s_waitcnt vmcnt(N) leaves exactly the
+// younger batches in flight.
 //
 // MFMA use (cdna_hip_programming.md section 3):
 //   F32    v_mfma_f32_32x32x2_f32 : lane l supplies A[l&31][k=l>>5], B[k=l>>5][l&31].  The k index is a
@@ -28,6 +32,8 @@
 //   BF16X3 same instruction three times (lo*hi + hi*lo + hi*hi) for ~fp32 accuracy at 3/16 of the fp32 cost.
 // LDS rows are padded by 16 B so the 16 rows a ds_read_b128 lane group touches fall on distinct 4-bank slots.
 #include <cstdio>
+#include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -35,15 +41,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ unsigned short f2bf_rne(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -51,10 +48,17 @@ template <int MATH> struct LdsElem { typedef float type; static constexpr int PA
 template <> struct LdsElem<SI_MATH_BF16> { typedef unsigned short type; static constexpr int PAD = 8; };
 template <> struct LdsElem<SI_MATH_BF16X3> { typedef unsigned short type; static constexpr int PAD = 8; };
 
-#define TG_MAXA 12      // float4 of the activation tile a thread can hold in flight (rowsA * BK/4 <= 3072)
+// float4 of the activation tile a thread holds in flight: 10 covers 128-row tiles (<= 320 rows at BK = 32),
+// 12 the 256-row tiles (306 rows) and the positional conv (383 rows at BK = 16)
+template <int BM> struct MaxA { static constexpr int value = BM == 128 ? 10 : 12; };
 
-template <int MATH, int BM, int BN, int WARPS_M, int WARPS_N, int BK>
-__global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
+template <int V> using ic = std::integral_constant<int, V>;
+
+// LINEAR (ntaps == 1) is a compile-time variant so that each instantiation carries only its own loop and register sets.
+// __launch_bounds__(256, 2): two waves per SIMD = two workgroups per CU (what the LDS footprint allows); without the
+// second argument the allocator takes up to 235 VGPRs + 64 accumulators and halves the occupancy.
+template <int MATH, int BM, int BN, int WARPS_M, int WARPS_N, int BK, bool LINEAR>
+__global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TapGemmParams p) {
     static_assert(WARPS_M * WARPS_N == 4, "4 waves per workgroup");
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -65,6 +69,8 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
     constexpr int V4 = BK / 4;                           // float4 per activation row
     constexpr int VB = (MATH == SI_MATH_F32) ? BK / 4 : BK / 8;     // 16-byte vectors per weight row (per plane)
     constexpr int MAXB = (BN * VB + 255) / 256;          // 16-byte vectors of a weight slab per thread (per plane)
+    constexpr int MAXA = MaxA<BM>::value;
+    constexpr int HALF = MAXA / 2;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -88,7 +94,9 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
     const int base_in = m0 * p.stride - p.pad + dil_lo;          // input row held in LDS row 0
     const int rowsA = (BM - 1) * p.stride + (p.ntaps - 1) * adil + 1;
     const int nA = rowsA * V4;                                    // float4 in one activation tile
-    const int abufs = p.ntaps == 1 ? 2 : 1;
+    const int ntaps = p.ntaps;
+    constexpr bool linear = LINEAR;
+    const int abufs = linear ? 2 : 1;
 
     const size_t a_tile = (size_t)PLANES * rowsA * LD;            // elements per activation buffer
     constexpr size_t b_tile = (size_t)PLANES * BN * LD;           // elements per weight buffer
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
     elem_t* Bs = As + (size_t)abufs * a_tile;                     // [2][PLANES][BN][LD]
 
     const float* xs = p.x + (long)seg * p.x_seg_stride + (long)g * p.Cin;
-    const size_t wplane = (size_t)p.ntaps * p.Npad * p.Cin;      // elements per group
+    const size_t wplane = (size_t)ntaps * p.Npad * p.Cin;        // elements per group
     const float slope = p.pro_slope;
 
     f32x16 acc[TM][TN];
@@ -107,36 +115,37 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[TG_MAXA];                    // activation tile in flight
-    f32x4 rb[PLANES][MAXB];               // weight slab in flight (16 bytes each, whatever the element type)
+    f32x4 ra[MAXA];                              // activation chunk(s) in flight: one set, or two half-sets (Linear)
+    f32x4 rb0[PLANES][MAXB], rb1[PLANES][MAXB];  // weight slabs of iterations it+1 / it+2 in flight
 
-    auto issueA = [&](int c0) {
+    // registers [LO, LO+CNT) of `ra` <- chunk c0 of the activation tile (zero outside the clip)
+    auto issueA = [&](auto lo, auto cnt, int c0) {
+        constexpr int LO = decltype(lo)::value, CNT = decltype(cnt)::value;
 #pragma unroll
-        for (int i = 0; i < TG_MAXA; ++i) {
+        for (int i = 0; i < CNT; ++i) {
             const int idx = tid + i * 256;
-            ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[LO + i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (idx < nA) {
                 const int r = idx / V4, j = idx - r * V4;
                 const int grow = base_in + r;
-                if (grow >= 0 && grow < p.Lin) ra[i] = *reinterpret_cast<const f32x4*>(xs + (long)grow * p.ldx + c0 + 4 * j);
+                if (grow >= 0 && grow < p.Lin) ra[LO + i] = *reinterpret_cast<const f32x4*>(xs + (long)grow * p.ldx + c0 + 4 * j);
             }
         }
     };
-    auto storeA = [&](elem_t* dst) {
+    auto storeA = [&](auto lo, auto cnt, elem_t* dst) {
+        constexpr int LO = decltype(lo)::value, CNT = decltype(cnt)::value;
 #pragma unroll
-        for (int i = 0; i < TG_MAXA; ++i) {
+        for (int i = 0; i < CNT; ++i) {
             const int idx = tid + i * 256;
             if (idx < nA) {
                 const int r = idx / V4, j = idx - r * V4;
-                f32x4 v = ra[i];
+                f32x4 v = ra[LO + i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
                 if constexpr (MATH == SI_MATH_F32) {
                     *reinterpret_cast<f32x4*>(dst + r * LD + 4 * j) = v;
                 } else {
-                    // vector casts lower to v_cvt_pk_bf16_f32 (round-to-nearest-even, 2 elements per instruction);
-                    // a bit-twiddled RNE costs ~15 VALU ops per element, which in bf16x3 mode rivalled the MFMA
-                    // time of a whole chunk
+                    // vector casts lower to v_cvt_pk_bf16_f32 (round-to-nearest-even, 2 elements per instruction)
                     const bf16x4 hi = __builtin_convertvector(v, bf16x4);
                     *reinterpret_cast<bf16x4*>(dst + r * LD + 4 * j) = hi;
                     if constexpr (MATH == SI_MATH_BF16X3) {
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
             }
         }
     };
-    auto issueB = [&](int c0, int tap) {
+    auto issueB = [&](f32x4 (&rb)[PLANES][MAXB], int c0, int tap) {
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl) {
             const char* wbase = reinterpret_cast<const char*>(pl == 0 ? p.w : p.w_lo) +
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
             }
         }
     };
-    auto storeB = [&](elem_t* dst) {
+    auto storeB = [&](const f32x4 (&rb)[PLANES][MAXB], elem_t* dst) {
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
@@ -175,29 +184,8 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
             }
     };
 
-    const int nchunks = p.Cin / BK;
-    const int total = nchunks * p.ntaps;
-
-    // (Measured and rejected: delaying the second resident workgroup of each CU by 1/2 or 1 tile to break the
-    // lock-step of co-resident workgroups cost 3-5 % on every fp32 shape.)
-    issueA(0);
-    issueB(0, 0);
-    storeA(As);
-    storeB(Bs);
-    __syncthreads();
-
-    int chunk = 0, tap = 0;
-    for (int it = 0; it < total; ++it) {
-        const bool has_next = it + 1 < total;
-        const bool new_chunk = has_next && (tap == p.ntaps - 1);
-        const int ntap = new_chunk ? 0 : tap + 1;
-        const int nchunk = new_chunk ? chunk + 1 : chunk;
-        if (has_next) issueB(nchunk * BK, ntap);
-        if (new_chunk) issueA(nchunk * BK);
-
-        // ---- MFMA over this (chunk, tap) out of LDS ----
-        const elem_t* Ac = As + (size_t)(abufs == 2 ? (chunk & 1) : 0) * a_tile;
-        const elem_t* Bc = Bs + (size_t)(it & 1) * b_tile;
+    // ---- MFMA over one (chunk, tap) out of LDS ----
+    auto compute = [&](const elem_t* Ac, const elem_t* Bc, int tap) {
         const int toff = tap * p.dil - dil_lo;                   // LDS row offset of this tap (>= 0)
         if constexpr (MATH == SI_MATH_F32) {
             const float* ap[TM];
@@ -238,11 +226,9 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
                 if constexpr (MATH == SI_MATH_BF16X3) {
                     bf16x8 al[TM], bl[TN];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        al[i] = *reinterpret_cast<const bf16x8*>(ap[i] + (size_t)rowsA * LD + 16 * ks);
+                    for (int i = 0; i < TM; ++i) al[i] = *reinterpret_cast<const bf16x8*>(ap[i] + (size_t)rowsA * LD + 16 * ks);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        bl[j] = *reinterpret_cast<const bf16x8*>(bp[j] + (size_t)BN * LD + 16 * ks);
+                    for (int j = 0; j < TN; ++j) bl[j] = *reinterpret_cast<const bf16x8*>(bp[j] + (size_t)BN * LD + 16 * ks);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -261,23 +247,97 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const TapGemmParams p) {
                 }
             }
         }
+    };
 
-        // ---- land the prefetched tiles ----
-        if (has_next) {
-            if (new_chunk && abufs == 1) __syncthreads();         // every wave is done reading the activation tile
-            storeB(Bs + (size_t)((it + 1) & 1) * b_tile);
-            if (new_chunk) storeA(As + (size_t)(abufs == 2 ? (nchunk & 1) : 0) * a_tile);
-            __syncthreads();
+    const int nchunks = p.Cin / BK;
+    const int total = nchunks * ntaps;
+    // (chunk, tap) of iterations it, it+1, it+2
+    int c0 = 0, t0 = 0, c1 = 0, t1 = 0, c2 = 0, t2 = 0;
+    auto adv = [&](int& c, int& t) { if (++t == ntaps) { t = 0; ++c; } };
+    adv(c1, t1);
+    adv(c2, t2); adv(c2, t2);
+
+    // (Measured and rejected: delaying the second resident workgroup of each CU by 1/2 or 1 tile to break the
+    // lock-step of co-resident workgroups cost 3-5 % on every fp32 shape.)
+    if constexpr (LINEAR) {
+        // ================================================================== Linear: every iteration is a new chunk
+        issueA(ic<0>{}, ic<HALF>{}, 0);
+        issueB(rb0, 0, 0);
+        if (total > 1) { issueA(ic<HALF>{}, ic<HALF>{}, BK); issueB(rb1, BK, 0); }
+        storeA(ic<0>{}, ic<HALF>{}, As);
+        storeB(rb0, Bs);
+        __syncthreads();
+        // even step: set 0 (ra[0..HALF), rb0) receives iteration it+2, set 1 lands iteration it+1; odd step mirrored
+        auto step = [&](auto issue_lo, auto land_lo, f32x4 (&rissue)[PLANES][MAXB], const f32x4 (&rland)[PLANES][MAXB], int it) {
+            if (it + 2 < total) { issueB(rissue, (it + 2) * BK, 0); issueA(issue_lo, ic<HALF>{}, (it + 2) * BK); }
+            compute(As + (size_t)(it & 1) * a_tile, Bs + (size_t)(it & 1) * b_tile, 0);
+            if (it + 1 < total) {
+                storeB(rland, Bs + (size_t)((it + 1) & 1) * b_tile);
+                storeA(land_lo, ic<HALF>{}, As + (size_t)((it + 1) & 1) * a_tile);
+                __syncthreads();
+            }
+        };
+        for (int it = 0; it < total; it += 2) {
+            step(ic<0>{}, ic<HALF>{}, rb0, rb1, it);
+            if (it + 1 < total) step(ic<HALF>{}, ic<0>{}, rb1, rb0, it + 1);
         }
-        tap = ntap;
-        chunk = nchunk;
+    } else if constexpr (MATH == SI_MATH_BF16X3 && BN < 128) {
+        // ================================================================== convolution, weights ONE iteration ahead:
+        // on the narrow bf16x3 tiles the second register set pushed the kernel to one wave per SIMD (193 VGPRs + 64
+        // accumulators) and cost 45 %; these tiles are HBM-bound anyway
+        issueA(ic<0>{}, ic<MAXA>{}, 0);
+        issueB(rb0, 0, 0);
+        storeA(ic<0>{}, ic<MAXA>{}, As);
+        storeB(rb0, Bs);
+        __syncthreads();
+        for (int it = 0; it < total; ++it) {
+            const bool has_next = it + 1 < total;
+            if (has_next) issueB(rb0, c1 * BK, t1);
+            if (t0 == 0 && c0 + 1 < nchunks) issueA(ic<0>{}, ic<MAXA>{}, (c0 + 1) * BK);
+            compute(As, Bs + (size_t)(it & 1) * b_tile, t0);
+            if (has_next) {
+                const bool new_chunk = t1 == 0;
+                if (new_chunk) __syncthreads();
+                storeB(rb0, Bs + (size_t)((it + 1) & 1) * b_tile);
+                if (new_chunk) storeA(ic<0>{}, ic<MAXA>{}, As);
+                __syncthreads();
+            }
+            c0 = c1; t0 = t1;
+            adv(c1, t1);
+        }
+    } else {
+        // ================================================================== convolution: ntaps iterations per chunk
+        issueA(ic<0>{}, ic<MAXA>{}, 0);
+        issueB(rb0, 0, 0);
+        if (total > 1) issueB(rb1, c1 * BK, t1);
+        storeA(ic<0>{}, ic<MAXA>{}, As);
+        storeB(rb0, Bs);
+        __syncthreads();
+        auto step = [&](f32x4 (&rissue)[PLANES][MAXB], const f32x4 (&rland)[PLANES][MAXB], int it) {
+            if (it + 2 < total) issueB(rissue, c2 * BK, t2);
+            if (t0 == 0 && c0 + 1 < nchunks) issueA(ic<0>{}, ic<MAXA>{}, (c0 + 1) * BK);   // lands over the chunk's other taps
+            compute(As, Bs + (size_t)(it & 1) * b_tile, t0);
+            if (it + 1 < total) {
+                const bool new_chunk = t1 == 0;
+                if (new_chunk) __syncthreads();                    // every wave is done reading the activation tile
+                storeB(rland, Bs + (size_t)((it + 1) & 1) * b_tile);
+                if (new_chunk) storeA(ic<0>{}, ic<MAXA>{}, As);
+                __syncthreads();
+            }
+            c0 = c1; t0 = t1; c1 = c2; t1 = t2;
+            adv(c2, t2);
+        };
+        for (int it = 0; it < total; it += 2) {
+            step(rb0, rb1, it);
+            if (it + 1 < total) step(rb1, rb0, it + 1);
+        }
     }
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-    // Residual / accumulate reads are issued as one unconditional batch per 32x32 tile (out-of-range elements
-    // read the segment's element 0 and are dropped at the store): a per-element predicated read serialises 16
-    // dependent global round trips per tile and doubled the time of every residual conv.
-    // Offsets inside a segment are 32-bit (the launcher checks olimit < 2^31) off a workgroup-uniform base.
+    // Residual / accumulate reads are issued as one unconditional batch of 8 per lane (out-of-range elements read the
+    // segment's element 0 and are dropped at the store): a per-element predicated read serialises 16 dependent global
+    // round trips per tile and doubled the time of every residual conv.  Offsets inside a segment are 32-bit (the
+    // launcher checks olimit < 2^31) off a workgroup-uniform base.
     float* const outp = p.out + (long)seg * p.o_seg_stride;
     const float* const resp = p.res ? p.res + (long)seg * p.o_seg_stride : nullptr;
     const bool has_res = p.res != nullptr;
@@ -333,23 +393,28 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     typedef typename LdsElem<MATH>::type elem_t;
     constexpr int LD = BK + LdsElem<MATH>::PAD;
     constexpr int PLANES = (MATH == SI_MATH_BF16X3) ? 2 : 1;
+    constexpr int MAXA = MaxA<BM>::value;
     const int adil = p.dil < 0 ? -p.dil : p.dil;
     const int rowsA = (BM - 1) * p.stride + (p.ntaps - 1) * adil + 1;
-    if (rowsA * (BK / 4) > TG_MAXA * 256)
+    const int cap = (p.ntaps == 1 ? MAXA / 2 : MAXA) * 256;
+    if (rowsA * (BK / 4) > cap)
         return si_fail(ctx, SI_EINVAL, "tapgemm: activation tile of %d rows exceeds the prefetch registers (stride %d, taps %d, dil %d)",
                        rowsA, p.stride, p.ntaps, p.dil);
     const int abufs = p.ntaps == 1 ? 2 : 1;
     const size_t lds = (size_t)PLANES * ((size_t)abufs * rowsA + 2 * BN) * LD * sizeof(elem_t);
     if (lds > 160 * 1024) return si_fail(ctx, SI_EINVAL, "tapgemm: LDS tile of %zu bytes exceeds 160 KiB", lds);
-    auto kern = tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK>;
-    if (lds > 64 * 1024) {
+    const bool lin = p.ntaps == 1;
+    auto kern = lin ? tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK, true> : tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK, false>;
+    static size_t lds_set[2] = {0, 0};                             // per instantiation
+    if (lds > 64 * 1024 && lds > lds_set[lin]) {
         SI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set[lin] = lds;
     }
     const int mtiles = (p.M + BM - 1) / BM;
     dim3 grid((unsigned)(p.nseg * mtiles * ((p.N + BN - 1) / BN)), (unsigned)p.groups);
     static const char* const math_names[] = {"f32", "bf16", "bf16x3"};
     char name[48];
-    snprintf(name, sizeof(name), "tapgemm_%s_%dx%d%s", math_names[MATH], BM, BN, BK == 64 ? "k64" : "");
+    snprintf(name, sizeof(name), "tapgemm_%s_%dx%d", math_names[MATH], BM, BN);
     const double macs = p.algo_macs > 0 ? p.algo_macs : (double)p.nseg * p.M * p.N * p.groups * (double)p.Cin * p.ntaps;
     double bytes = 4.0 * p.nseg * ((double)p.Lin * p.Cin * p.groups + (double)p.M * p.N * p.groups * (1 + (p.res ? 1 : 0) + (p.accumulate ? 1 : 0))) +
                    (double)p.groups * p.ntaps * p.N * p.Cin * (MATH == SI_MATH_F32 ? 4 : (MATH == SI_MATH_BF16 ? 2 : 4));
@@ -365,9 +430,11 @@ static int launch_math(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     const int bn = si_pick_bn(p.N);
     if (bn == 128) return launch_cfg<MATH, 128, 128, 2, 2, BK>(ctx, p, st);
     // narrow N: 256-row tiles unless their halo'd activation tile would not fit the prefetch registers
-    // (strided convs), or the segment is so short that a 256-row tile would be mostly padding
+    // (strided convs, Linear layers with their two half-sets), or the segment is so short that a 256-row tile
+    // would be mostly padding
     const int adil = p.dil < 0 ? -p.dil : p.dil;
-    const bool tall = ((255 * p.stride + (p.ntaps - 1) * adil + 1) * (BK / 4) <= TG_MAXA * 256) && p.M > 128;
+    const int cap = (p.ntaps == 1 ? MaxA<256>::value / 2 : MaxA<256>::value) * 256;
+    const bool tall = ((255 * p.stride + (p.ntaps - 1) * adil + 1) * (BK / 4) <= cap) && p.M > 128;
     if (bn == 64) return tall ? launch_cfg<MATH, 256, 64, 4, 1, BK>(ctx, p, st) : launch_cfg<MATH, 128, 64, 2, 2, BK>(ctx, p, st);
     return tall ? launch_cfg<MATH, 256, 32, 4, 1, BK>(ctx, p, st) : launch_cfg<MATH, 128, 32, 4, 1, BK>(ctx, p, st);
 }
@@ -380,22 +447,18 @@ int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t
     if (p.M <= 0 || p.nseg <= 0) return SI_OK;
     if (p.olimit >= (1L << 31) || (long)p.M * p.ldo + p.ooff >= (1L << 31) || (long)p.Lin * p.ldx >= (1L << 31))
         return si_fail(ctx, SI_EINVAL, "tapgemm: a segment of %ld floats exceeds the 32-bit in-segment offsets", p.olimit);
+    // wave-specialised producer/consumer form (tapgemm_ws.hip): measured slower than this kernel on every shape of the
+    // path (one workgroup per CU exposes its prologue/epilogue); kept selectable with SI_TG_WS=1 for experiments
+    static const int ws_mode = getenv("SI_TG_WS") ? atoi(getenv("SI_TG_WS")) : 0;
+    if (ws_mode) {
+        const int rc = si_launch_tapgemm_ws(ctx, math, p, st);
+        if (rc <= 0) return rc;
+    }
     const bool k32 = (p.Cin % 32 == 0);
-    // bf16 MFMAs retire a 32-deep K chunk in a quarter of the fp32 time, so the barrier + staging cost per chunk
-    // dominates; a 64-deep chunk halves it where the (wider) activation tile still fits the prefetch registers.
-    static const int bk64_mode = getenv("SI_TG_BK64") ? atoi(getenv("SI_TG_BK64")) : 0;
-    const int adil = p.dil < 0 ? -p.dil : p.dil;
-    const int bm = si_pick_bn(p.N) == 128 ? 128 : 256;
-    const bool k64 = bk64_mode && math != SI_MATH_F32 && p.Cin % 64 == 0 &&
-                     ((bm - 1) * p.stride + (p.ntaps - 1) * adil + 1) * 16 <= TG_MAXA * 256;
     switch (math) {
         case SI_MATH_F32: return k32 ? launch_math<SI_MATH_F32, 32>(ctx, p, st) : launch_math<SI_MATH_F32, 16>(ctx, p, st);
-        case SI_MATH_BF16:
-            if (k64) return launch_math<SI_MATH_BF16, 64>(ctx, p, st);
-            return k32 ? launch_math<SI_MATH_BF16, 32>(ctx, p, st) : launch_math<SI_MATH_BF16, 16>(ctx, p, st);
-        case SI_MATH_BF16X3:
-            if (k64) return launch_math<SI_MATH_BF16X3, 64>(ctx, p, st);
-            return k32 ? launch_math<SI_MATH_BF16X3, 32>(ctx, p, st) : launch_math<SI_MATH_BF16X3, 16>(ctx, p, st);
+        case SI_MATH_BF16: return k32 ? launch_math<SI_MATH_BF16, 32>(ctx, p, st) : launch_math<SI_MATH_BF16, 16>(ctx, p, st);
+        case SI_MATH_BF16X3: return k32 ? launch_math<SI_MATH_BF16X3, 32>(ctx, p, st) : launch_math<SI_MATH_BF16X3, 16>(ctx, p, st);
     }
     return si_fail(ctx, SI_EINVAL, "tapgemm: unknown math mode %d", math);
 }

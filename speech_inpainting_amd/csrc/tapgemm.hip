@@ -50,16 +50,31 @@ template <> struct LdsElem<SI_MATH_BF16X3> { typedef unsigned short type; static
 
 // float4 of the activation tile a thread holds in flight: 10 covers 128-row tiles (<= 320 rows at BK = 32),
 // 12 the 256-row tiles (306 rows) and the positional conv (383 rows at BK = 16)
-template <int BM> struct MaxA { static constexpr int value = BM == 128 ? 10 : 12; };
+// (an 8-wave workgroup spreads the same tile over 512 threads: half the registers per thread)
+template <int BM, int NT = 256> struct MaxA { static constexpr int value = NT == 512 ? 6 : (BM == 128 ? 10 : 12); };
 
 template <int V> using ic = std::integral_constant<int, V>;
+
+// Diagnostic build only (make stamps -> libsi_hip_stamps.so, -DTG_STAMPS): per-phase s_memtime sums of every wave,
+// accumulated per N-tile family into si_tg_stamps[3][8] = {issue, compute, land (vmcnt wait + LDS writes), barrier,
+// prologue, epilogue, total, waves}; read with tools/exp_stamps.py.  The stamps serialise the phases they bracket, so
+// only the SHARES are meaningful; no stamp executes in the shipped library.
+#ifdef TG_STAMPS
+__device__ unsigned long long si_tg_stamps[24];
+#define TG_T(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define TG_ACC(slot, a, b) st_acc[slot] += (b) - (a)
+#else
+#define TG_T(var)
+#define TG_ACC(slot, a, b)
+#endif
 
 // LINEAR (ntaps == 1) is a compile-time variant so that each instantiation carries only its own loop and register sets.
 // __launch_bounds__(256, 2): two waves per SIMD = two workgroups per CU (what the LDS footprint allows); without the
 // second argument the allocator takes up to 235 VGPRs + 64 accumulators and halves the occupancy.
 template <int MATH, int BM, int BN, int WARPS_M, int WARPS_N, int BK, bool LINEAR>
-__global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TapGemmParams p) {
-    static_assert(WARPS_M * WARPS_N == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void tapgemm_kernel(const TapGemmParams p) {
+    static_assert(WARPS_M * WARPS_N == 4 || WARPS_M * WARPS_N == 8, "4 or 8 waves per workgroup");
+    constexpr int NT = 64 * WARPS_M * WARPS_N;          // threads per workgroup
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile is a multiple of 32x32");
@@ -68,8 +83,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TapGemmParams p) 
     constexpr int PLANES = (MATH == SI_MATH_BF16X3) ? 2 : 1;
     constexpr int V4 = BK / 4;                           // float4 per activation row
     constexpr int VB = (MATH == SI_MATH_F32) ? BK / 4 : BK / 8;     // 16-byte vectors per weight row (per plane)
-    constexpr int MAXB = (BN * VB + 255) / 256;          // 16-byte vectors of a weight slab per thread (per plane)
-    constexpr int MAXA = MaxA<BM>::value;
+    constexpr int MAXB = (BN * VB + NT - 1) / NT;          // 16-byte vectors of a weight slab per thread (per plane)
+    constexpr int MAXA = MaxA<BM, NT>::value;
     constexpr int HALF = MAXA / 2;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -115,6 +130,10 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TapGemmParams p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#ifdef TG_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    TG_T(st_begin);
+#endif
     f32x4 ra[MAXA];                              // activation chunk(s) in flight: one set, or two half-sets (Linear)
     f32x4 rb0[PLANES][MAXB], rb1[PLANES][MAXB];  // weight slabs of iterations it+1 / it+2 in flight
 
@@ -123,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TapGemmParams p) 
         constexpr int LO = decltype(lo)::value, CNT = decltype(cnt)::value;
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NT;
             ra[LO + i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (idx < nA) {
                 const int r = idx / V4, j = idx - r * V4;
@@ -136,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TapGemmParams p) 
         constexpr int LO = decltype(lo)::value, CNT = decltype(cnt)::value;
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NT;
             if (idx < nA) {
                 const int r = idx / V4, j = idx - r * V4;
                 f32x4 v = ra[LO + i];
@@ -163,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TapGemmParams p) 
                                 sizeof(elem_t) * ((size_t)g * wplane + ((size_t)tap * p.Npad + n0) * p.Cin + c0);
 #pragma unroll
             for (int i = 0; i < MAXB; ++i) {
-                const int idx = tid + i * 256;
-                if (BN * VB % 256 == 0 || idx < BN * VB) {
+                const int idx = tid + i * NT;
+                if (BN * VB % NT == 0 || idx < BN * VB) {
                     const int r = idx / VB, j = idx - r * VB;
                     rb[pl][i] = *reinterpret_cast<const f32x4*>(wbase + sizeof(elem_t) * (size_t)r * p.Cin + 16 * j);
                 }
@@ -176,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TapGemmParams p) 
         for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
             for (int i = 0; i < MAXB; ++i) {
-                const int idx = tid + i * 256;
-                if (BN * VB % 256 == 0 || idx < BN * VB) {
+                const int idx = tid + i * NT;
+                if (BN * VB % NT == 0 || idx < BN * VB) {
                     const int r = idx / VB, j = idx - r * VB;
                     *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(dst + (size_t)pl * BN * LD + r * LD) + 16 * j) = rb[pl][i];
                 }
@@ -261,15 +280,22 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TapGemmParams p) 
     // lock-step of co-resident workgroups cost 3-5 % on every fp32 shape.)
     if constexpr (LINEAR) {
         // ================================================================== Linear: every iteration is a new chunk
+        // Prefetch loads are UNCONDITIONAL (descriptor clamped to the last chunk, which is simply re-read): a load under
+        // `if (it + 2 < total)` makes the compiler's s_waitcnt conservative at the branch join -- it must assume the
+        // load was not issued, emits vmcnt(0), and so drains the very prefetch that was meant to stay in flight (an
+        // ablation showed each iteration paying one full memory latency).
         issueA(ic<0>{}, ic<HALF>{}, 0);
         issueB(rb0, 0, 0);
-        if (total > 1) { issueA(ic<HALF>{}, ic<HALF>{}, BK); issueB(rb1, BK, 0); }
+        issueA(ic<HALF>{}, ic<HALF>{}, total > 1 ? BK : 0);
+        issueB(rb1, total > 1 ? BK : 0, 0);
         storeA(ic<0>{}, ic<HALF>{}, As);
         storeB(rb0, Bs);
         __syncthreads();
         // even step: set 0 (ra[0..HALF), rb0) receives iteration it+2, set 1 lands iteration it+1; odd step mirrored
         auto step = [&](auto issue_lo, auto land_lo, f32x4 (&rissue)[PLANES][MAXB], const f32x4 (&rland)[PLANES][MAXB], int it) {
-            if (it + 2 < total) { issueB(rissue, (it + 2) * BK, 0); issueA(issue_lo, ic<HALF>{}, (it + 2) * BK); }
+            const int cn = (it + 2 < total ? it + 2 : total - 1) * BK;
+            issueB(rissue, cn, 0);
+            issueA(issue_lo, ic<HALF>{}, cn);
             compute(As + (size_t)(it & 1) * a_tile, Bs + (size_t)(it & 1) * b_tile, 0);
             if (it + 1 < total) {
                 storeB(rland, Bs + (size_t)((it + 1) & 1) * b_tile);
@@ -290,42 +316,66 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TapGemmParams p) 
         storeA(ic<0>{}, ic<MAXA>{}, As);
         storeB(rb0, Bs);
         __syncthreads();
+        TG_T(st_pro);
+        TG_ACC(4, st_begin, st_pro);
         for (int it = 0; it < total; ++it) {
             const bool has_next = it + 1 < total;
-            if (has_next) issueB(rb0, c1 * BK, t1);
+            TG_T(s0);
+            issueB(rb0, has_next ? c1 * BK : c0 * BK, has_next ? t1 : t0);      // unconditional (see the Linear loop)
             if (t0 == 0 && c0 + 1 < nchunks) issueA(ic<0>{}, ic<MAXA>{}, (c0 + 1) * BK);
+            TG_T(s1);
             compute(As, Bs + (size_t)(it & 1) * b_tile, t0);
+            TG_T(s2);
+            TG_ACC(0, s0, s1); TG_ACC(1, s1, s2);
             if (has_next) {
                 const bool new_chunk = t1 == 0;
                 if (new_chunk) __syncthreads();
                 storeB(rb0, Bs + (size_t)((it + 1) & 1) * b_tile);
                 if (new_chunk) storeA(ic<0>{}, ic<MAXA>{}, As);
+                TG_T(s3);
                 __syncthreads();
+                TG_T(s4);
+                TG_ACC(2, s2, s3); TG_ACC(3, s3, s4);
             }
             c0 = c1; t0 = t1;
             adv(c1, t1);
         }
     } else {
         // ================================================================== convolution: ntaps iterations per chunk
+        // The weight slab of iteration it+2 is issued UNCONDITIONALLY (descriptor clamped to the last iteration), see
+        // the Linear loop for why.  The once-per-chunk activation prefetch stays conditional: at its join the compiler
+        // settles for the smaller count, which drains part of that prefetch once per `ntaps` iterations, not every one.
+        // (Four straight-line copies of the body -- chunk-opening x register-set parity -- were exact but spilled.)
+        if (total == 1) { c1 = c0; t1 = t0; }
+        if (total <= 2) { c2 = c1; t2 = t1; }
         issueA(ic<0>{}, ic<MAXA>{}, 0);
         issueB(rb0, 0, 0);
-        if (total > 1) issueB(rb1, c1 * BK, t1);
+        issueB(rb1, c1 * BK, t1);
         storeA(ic<0>{}, ic<MAXA>{}, As);
         storeB(rb0, Bs);
         __syncthreads();
+        TG_T(st_pro);
+        TG_ACC(4, st_begin, st_pro);
         auto step = [&](f32x4 (&rissue)[PLANES][MAXB], const f32x4 (&rland)[PLANES][MAXB], int it) {
-            if (it + 2 < total) issueB(rissue, c2 * BK, t2);
+            TG_T(s0);
+            issueB(rissue, c2 * BK, t2);
             if (t0 == 0 && c0 + 1 < nchunks) issueA(ic<0>{}, ic<MAXA>{}, (c0 + 1) * BK);   // lands over the chunk's other taps
+            TG_T(s1);
             compute(As, Bs + (size_t)(it & 1) * b_tile, t0);
+            TG_T(s2);
+            TG_ACC(0, s0, s1); TG_ACC(1, s1, s2);
             if (it + 1 < total) {
                 const bool new_chunk = t1 == 0;
                 if (new_chunk) __syncthreads();                    // every wave is done reading the activation tile
                 storeB(rland, Bs + (size_t)((it + 1) & 1) * b_tile);
                 if (new_chunk) storeA(ic<0>{}, ic<MAXA>{}, As);
+                TG_T(s3);
                 __syncthreads();
+                TG_T(s4);
+                TG_ACC(2, s2, s3); TG_ACC(3, s3, s4);
             }
             c0 = c1; t0 = t1; c1 = c2; t1 = t2;
-            adv(c2, t2);
+            if (it + 3 < total) adv(c2, t2);                       // the far descriptor stops at the last iteration
         };
         for (int it = 0; it < total; it += 2) {
             step(rb0, rb1, it);
@@ -333,59 +383,79 @@ __global__ __launch_bounds__(256, 2) void tapgemm_kernel(const TapGemmParams p) 
         }
     }
 
+    TG_T(st_epi);
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-    // Residual / accumulate reads are issued as one unconditional batch of 8 per lane (out-of-range elements read the
-    // segment's element 0 and are dropped at the store): a per-element predicated read serialises 16 dependent global
-    // round trips per tile and doubled the time of every residual conv.  Offsets inside a segment are 32-bit (the
-    // launcher checks olimit < 2^31) off a workgroup-uniform base.
+    // In-kernel stamps showed the epilogue at 31-47 % of a wave's life in the bf16 modes: eight dependent
+    // "8 loads -> wait -> 8 stores" round trips per wave.  Now EVERY residual / accumulate read of the wave tile is
+    // issued in one burst, then one wait, then all stores.  Accesses go through buffer descriptors that span exactly
+    // this segment's output: the hardware range check drops rows >= M, the negative offsets of the ConvTranspose
+    // phase layout and (voffset forced to 2^31) the columns >= N, so no per-element predicate or address register
+    // survives -- a lane keeps one byte offset per 32x32 tile and adds a scalar row step.
     float* const outp = p.out + (long)seg * p.o_seg_stride;
-    const float* const resp = p.res ? p.res + (long)seg * p.o_seg_stride : nullptr;
+    const float* const resp = p.res ? p.res + (long)seg * p.o_seg_stride : outp;
     const bool has_res = p.res != nullptr;
     const bool acc_out = p.accumulate != 0;
     const bool gelu = p.act == SI_ACT_GELU;
-    const int olim = (int)p.olimit;
+    const int nbytes = (int)p.olimit * 4;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(resp), 0, nbytes, 0x00020000);
+    const int rstep = p.ldo * 4;                                   // bytes between output rows
+    int vb[TM][TN];
+    float bv[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        const bool nok = n < p.N;
+        bv[j] = (p.bias && nok) ? p.bias[g * p.N + n] : 0.f;
+        const int col = g * p.N + n + (int)p.ooff;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn0 + j * 32 + l31;
-            const bool nok = n < p.N;
-            const float bv = (p.bias && nok) ? p.bias[g * p.N + n] : 0.f;
-            const int col = g * p.N + n + (int)p.ooff;
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {                       // two batches of 8 keep the register footprint small
-                int fl[8];
-                unsigned okm = 0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int r = hb * 8 + q;
-                    const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const long flat = (long)m * p.ldo + col;
-                    const bool ok = nok && m < p.M && flat >= 0 && flat < olim;
-                    okm |= (ok ? 1u : 0u) << q;
-                    fl[q] = ok ? (int)flat : 0;
-                }
-                float rv[8], ov[8];
-                if (has_res) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) rv[q] = resp[fl[q]];
-                }
-                if (acc_out) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) ov[q] = outp[fl[q]];
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    float v = acc[i][j][hb * 8 + q] + bv;
-                    if (gelu) v = gelu_erf(v);
-                    if (has_res) v += rv[q];
-                    v *= p.alpha;
-                    if (acc_out) v += ov[q];
-                    if ((okm >> q) & 1u) outp[fl[q]] = v;
-                }
-            }
-        }
+        for (int i = 0; i < TM; ++i)
+            vb[i][j] = nok ? ((m0 + wm0 + i * 32 + 4 * half) * p.ldo + col) * 4 : (int)0x80000000;
     }
+    // C/D row of accumulator register r (besides the 4*half already in vb): (r&3) + 8*(r>>2)
+    float rv[TM][TN][16], ov[TM][TN][16];
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rv[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, vb[i][j] + ((r & 3) + 8 * (r >> 2)) * rstep, 0, 0));
+    }
+    if (acc_out) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ov[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(orsrc, vb[i][j] + ((r & 3) + 8 * (r >> 2)) * rstep, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] + bv[j];
+                if (gelu) v = gelu_erf(v);
+                if (has_res) v += rv[i][j][r];
+                v *= p.alpha;
+                if (acc_out) v += ov[i][j][r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, vb[i][j] + ((r & 3) + 8 * (r >> 2)) * rstep, 0, 0);
+            }
+#ifdef TG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // include the store drain: a wave cannot retire before it
+    TG_T(st_end);
+    TG_ACC(5, st_epi, st_end);
+    if (lane == 0) {
+        constexpr int FAM = (BN == 128 ? 0 : BN == 64 ? 1 : 2) * 8;
+        for (int q = 0; q < 6; ++q) atomicAdd(&si_tg_stamps[FAM + q], st_acc[q]);
+        atomicAdd(&si_tg_stamps[FAM + 6], st_end - st_begin);
+        atomicAdd(&si_tg_stamps[FAM + 7], 1ull);
+    }
+#endif
 }
 
 template <int MATH, int BM, int BN, int WARPS_M, int WARPS_N, int BK>
@@ -393,10 +463,11 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     typedef typename LdsElem<MATH>::type elem_t;
     constexpr int LD = BK + LdsElem<MATH>::PAD;
     constexpr int PLANES = (MATH == SI_MATH_BF16X3) ? 2 : 1;
-    constexpr int MAXA = MaxA<BM>::value;
+    constexpr int NT = 64 * WARPS_M * WARPS_N;
+    constexpr int MAXA = MaxA<BM, NT>::value;
     const int adil = p.dil < 0 ? -p.dil : p.dil;
     const int rowsA = (BM - 1) * p.stride + (p.ntaps - 1) * adil + 1;
-    const int cap = (p.ntaps == 1 ? MAXA / 2 : MAXA) * 256;
+    const int cap = (p.ntaps == 1 ? MAXA / 2 : MAXA) * NT;
     if (rowsA * (BK / 4) > cap)
         return si_fail(ctx, SI_EINVAL, "tapgemm: activation tile of %d rows exceeds the prefetch registers (stride %d, taps %d, dil %d)",
                        rowsA, p.stride, p.ntaps, p.dil);
@@ -414,12 +485,12 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     dim3 grid((unsigned)(p.nseg * mtiles * ((p.N + BN - 1) / BN)), (unsigned)p.groups);
     static const char* const math_names[] = {"f32", "bf16", "bf16x3"};
     char name[48];
-    snprintf(name, sizeof(name), "tapgemm_%s_%dx%d", math_names[MATH], BM, BN);
+    snprintf(name, sizeof(name), "tapgemm_%s_%dx%d%s", math_names[MATH], BM, BN, NT == 512 ? "w8" : "");
     const double macs = p.algo_macs > 0 ? p.algo_macs : (double)p.nseg * p.M * p.N * p.groups * (double)p.Cin * p.ntaps;
     double bytes = 4.0 * p.nseg * ((double)p.Lin * p.Cin * p.groups + (double)p.M * p.N * p.groups * (1 + (p.res ? 1 : 0) + (p.accumulate ? 1 : 0))) +
                    (double)p.groups * p.ntaps * p.N * p.Cin * (MATH == SI_MATH_F32 ? 4 : (MATH == SI_MATH_BF16 ? 2 : 4));
     si_prof_begin(ctx, name, 2.0 * macs, bytes, st);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, p);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
@@ -428,7 +499,16 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
 template <int MATH, int BK>
 static int launch_math(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     const int bn = si_pick_bn(p.N);
-    if (bn == 128) return launch_cfg<MATH, 128, 128, 2, 2, BK>(ctx, p, st);
+    if (bn == 128) {
+        // One 8-wave workgroup per CU on a 256x128 tile (each weight slab staged once for twice the MFMAs) instead of two
+        // 4-wave workgroups on 128x128 tiles: +6 % on the bf16x3 convolutions, +1 % in fp32 (SI_TG_BIG=0 to compare).
+        static const int big = getenv("SI_TG_BIG") ? atoi(getenv("SI_TG_BIG")) : 1;
+        const int adil8 = p.dil < 0 ? -p.dil : p.dil;
+        const int cap8 = (p.ntaps == 1 ? MaxA<256, 512>::value / 2 : MaxA<256, 512>::value) * 512;
+        if (big && BK == 32 && p.M > 256 && (255 * p.stride + (p.ntaps - 1) * adil8 + 1) * (BK / 4) <= cap8)
+            return launch_cfg<MATH, 256, 128, 4, 2, BK>(ctx, p, st);
+        return launch_cfg<MATH, 128, 128, 2, 2, BK>(ctx, p, st);
+    }
     // narrow N: 256-row tiles unless their halo'd activation tile would not fit the prefetch registers
     // (strided convs, Linear layers with their two half-sets), or the segment is so short that a 256-row tile
     // would be mostly padding
@@ -439,14 +519,31 @@ static int launch_math(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     return tall ? launch_cfg<MATH, 256, 32, 4, 1, BK>(ctx, p, st) : launch_cfg<MATH, 128, 32, 4, 1, BK>(ctx, p, st);
 }
 
+#ifdef TG_STAMPS
+extern "C" int si_debug_stamps(unsigned long long* out24, int reset) {
+    if (out24 && hipMemcpyFromSymbol(out24, HIP_SYMBOL(si_tg_stamps), sizeof(si_tg_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[24] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(si_tg_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t st) {
     if (p.Cin % 16 != 0 || p.ldx % 4 != 0)
         return si_fail(ctx, SI_EINVAL, "tapgemm: Cin=%d must be a multiple of 16 and ldx=%d of 4", p.Cin, p.ldx);
     if (p.Npad % si_pick_bn(p.N) != 0 || p.Npad < p.N)
         return si_fail(ctx, SI_EINVAL, "tapgemm: Npad=%d does not match N=%d", p.Npad, p.N);
     if (p.M <= 0 || p.nseg <= 0) return SI_OK;
-    if (p.olimit >= (1L << 31) || (long)p.M * p.ldo + p.ooff >= (1L << 31) || (long)p.Lin * p.ldx >= (1L << 31))
-        return si_fail(ctx, SI_EINVAL, "tapgemm: a segment of %ld floats exceeds the 32-bit in-segment offsets", p.olimit);
+    // The epilogue masks through a buffer descriptor of olimit*4 bytes: byte offsets of every tile row (valid or not)
+    // must stay below 2^31, and rows >= M must fall outside the descriptor.
+    const long ooff_abs = p.ooff < 0 ? -p.ooff : p.ooff;
+    if (((long)p.M + 256) * p.ldo * 4 + ooff_abs * 4 >= (1L << 31) || p.olimit * 4 >= (1L << 31) || (long)p.Lin * p.ldx >= (1L << 31))
+        return si_fail(ctx, SI_EINVAL, "tapgemm: a segment of %ld floats exceeds the 32-bit in-segment byte offsets", p.olimit);
+    if ((long)p.M * p.ldo + p.ooff < p.olimit)
+        return si_fail(ctx, SI_EINVAL, "tapgemm: olimit=%ld must not exceed M*ldo+ooff=%ld (rows >= M are masked by the range check)",
+                       p.olimit, (long)p.M * p.ldo + p.ooff);
     // wave-specialised producer/consumer form (tapgemm_ws.hip): measured slower than this kernel on every shape of the
     // path (one workgroup per CU exposes its prologue/epilogue); kept selectable with SI_TG_WS=1 for experiments
     static const int ws_mode = getenv("SI_TG_WS") ? atoi(getenv("SI_TG_WS")) : 0;

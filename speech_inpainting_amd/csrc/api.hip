@@ -75,6 +75,9 @@ struct si_ctx {
     std::vector<hipEvent_t> prof_pool;
     size_t prof_used = 0;
     int prof_open = -1;
+    // second stream of the vocoder (si_hifigan_forward runs two halves of a chunk concurrently)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static char g_create_err[512] = "";
@@ -503,8 +506,10 @@ size_t vocoder_ws_bytes(const si_ctx* ctx, int B, int Tm, int stretch) {
     size_t lc_max = (size_t)Tout * d.up_initial_channel;
     long L = Tout; int c = d.up_initial_channel;
     for (int i = 0; i < d.num_ups; ++i) { L *= d.up_rates[i]; c /= 2; lc_max = std::max(lc_max, (size_t)L * c); }
-    size_t f = (size_t)Bc * Tout * ctx->lay.mel_ld + 6 * (size_t)Bc * lc_max;
-    return f * 4 + 16 * 256;
+    const size_t sub = (size_t)(Bc + 1) / 2;                 // two half-chunks, one per stream
+    size_t f = 2 * (sub * Tout * ctx->lay.mel_ld + 6 * sub * lc_max);
+    f = std::max(f, (size_t)Bc * Tout * ctx->lay.mel_ld + 6 * (size_t)Bc * lc_max);
+    return f * 4 + 32 * 256;
 }
 
 TapGemmParams gemm_params(const si_ctx* ctx, const GemmW& G) {
@@ -558,6 +563,7 @@ void si_destroy(si_ctx* ctx) {
     if (!ctx) return;
     if (ctx->wdev) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->wdev); }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
+    if (ctx->aux_stream) { (void)hipStreamDestroy(ctx->aux_stream); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
     delete ctx;
 }
 
@@ -755,17 +761,33 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
         for (int i = 0; i < d.num_ups; ++i) { L *= d.up_rates[i]; c /= 2; lc_max = std::max(lc_max, (size_t)L * c); }
     }
     const long Lwav = si_vocoder_samples(ctx, Tm, stretch);
+    // Opt-in (SI_VOC_STREAMS=2): two independent halves of every chunk on two HIP streams (the caller's and one owned by
+    // the context), so that one half's memory-bound phases (cold prologue, residual reads, store drain: 30-50 % of a
+    // wave's life per the in-kernel stamps) overlap the other half's MFMA phases.  Measured gain at B = 32: 2 % (bf16x3)
+    // to 4 % (fp32) of wall time -- not worth doubling the launch count by default.  Clips are independent, so results
+    // do not change.
+    static const int nstreams_env = getenv("SI_VOC_STREAMS") ? atoi(getenv("SI_VOC_STREAMS")) : 1;
+    const int nstr = (nstreams_env >= 2 && Bc_max >= 2) ? 2 : 1;
+    const int sub_max = (Bc_max + nstr - 1) / nstr;
     Carver W{static_cast<char*>(workspace), workspace_bytes};
-    float* ext = W.floats((size_t)Bc_max * Tout * Ly.mel_ld);
-    float* buf[6];
-    for (auto& b : buf) b = W.floats((size_t)Bc_max * lc_max);
+    float* ext_s[2];
+    float* buf_s[2][6];
+    for (int h = 0; h < nstr; ++h) {
+        ext_s[h] = W.floats((size_t)sub_max * Tout * Ly.mel_ld);
+        for (auto& b : buf_s[h]) b = W.floats((size_t)sub_max * lc_max);
+    }
     if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: vocoder workspace carve exceeded its own estimate");
+    if (nstr == 2 && !ctx->aux_stream) {
+        SI_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        SI_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        SI_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
     const int nk = d.num_rb;
     static const char* upn[] = {"ups0", "ups1", "ups2", "ups3", "ups4", "ups5", "ups6", "ups7"};
     static const char* stn[] = {"stage0", "stage1", "stage2", "stage3", "stage4", "stage5", "stage6", "stage7"};
 
-    for (int b0 = 0; b0 < B; b0 += Bc_max) {
-        const int Bc = std::min(Bc_max, B - b0);
+    // the generator on clips [b0, b0 + Bc) with its own scratch, enqueued on stream `st`
+    auto run = [&](int b0, int Bc, float* ext, float* const* buf, hipStream_t st) -> int {
         int rc;
         // A14: stretch + transpose to channels-last
         if ((rc = si_launch_extend_mel(ctx, mel + (size_t)b0 * d.num_mels * Tm, Bc, d.num_mels, Tm, (int)Tout, stretch, ext, Ly.mel_ld, st))) return rc;
@@ -827,7 +849,23 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
             Lc = Lo; c = cout;
         }
         // B4: leaky_relu(0.01) -> conv_post -> tanh
-        if ((rc = si_launch_conv_post(ctx, x, wf(ctx, Ly.post_w), wf(ctx, Ly.post_b), Bc, (int)Lc, c, 7, wav_out + (size_t)b0 * Lwav, st))) return rc;
+        return si_launch_conv_post(ctx, x, wf(ctx, Ly.post_w), wf(ctx, Ly.post_b), Bc, (int)Lc, c, 7, wav_out + (size_t)b0 * Lwav, st);
+    };
+
+    for (int b0 = 0; b0 < B; b0 += Bc_max) {
+        const int Bc = std::min(Bc_max, B - b0);
+        const int first = nstr == 2 ? (Bc + 1) / 2 : Bc;           // clips of this chunk that stay on the caller's stream
+        int rc;
+        if (first < Bc) {
+            SI_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));        // the second half starts after everything already queued
+            SI_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+        }
+        if ((rc = run(b0, first, ext_s[0], buf_s[0], st))) return rc;
+        if (first < Bc) {
+            if ((rc = run(b0 + first, Bc - first, ext_s[1], buf_s[1], ctx->aux_stream))) return rc;
+            SI_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+            SI_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        }
     }
     return SI_OK;
 }

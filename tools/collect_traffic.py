@@ -19,9 +19,9 @@ MATH = {"0": "f32", "1": "bf16", "2": "bf16x3"}
 
 
 def family(kernel_name: str) -> str:
-    m = re.search(r"tapgemm_kernel<(\d), (\d+), (\d+), \d, \d, (\d+)>", kernel_name)
-    if m:
-        return f"tapgemm_{MATH[m.group(1)]}_{m.group(2)}x{m.group(3)}" + ("k64" if m.group(4) == "64" else "")
+    m = re.search(r"tapgemm_kernel<(\d), (\d+), (\d+), (\d), (\d), (\d+)", kernel_name)
+    if m:      # bench.py's family name: tapgemm_<math>_<BM>x<BN>[w8]
+        return f"tapgemm_{MATH[m.group(1)]}_{m.group(2)}x{m.group(3)}" + ("w8" if int(m.group(4)) * int(m.group(5)) == 8 else "")
     return re.sub(r"_kernel.*|\(.*", "", kernel_name).replace("void ", "")
 
 

@@ -551,6 +551,13 @@ int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t
         const int rc = si_launch_tapgemm_ws(ctx, math, p, st);
         if (rc <= 0) return rc;
     }
+    // SI_TG_PERSIST=1: persistent cross-tile-pipelined form (tapgemm_p.hip).  Measured slower than the per-tile grid
+    // (bf16x3 256x128w8 15.3 vs 14.7 ms/step; the 256x64 / 256x32 variants spill), so it is opt-in.
+    static const int persist = getenv("SI_TG_PERSIST") ? atoi(getenv("SI_TG_PERSIST")) : 0;
+    if (persist) {
+        const int rc = si_launch_tapgemm_p(ctx, math, p, st);
+        if (rc <= 0) return rc;
+    }
     const bool k32 = (p.Cin % 32 == 0);
     switch (math) {
         case SI_MATH_F32: return k32 ? launch_math<SI_MATH_F32, 32>(ctx, p, st) : launch_math<SI_MATH_F32, 16>(ctx, p, st);

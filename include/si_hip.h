@@ -8,6 +8,8 @@
  *                           + the zero-mask + processor normalise in front of it (I_ea/predict.py:132-141)
  *   si_codebook_splice   <- frame gather + LossFunction.cos_sim arg-max + centroid splice
  *                           I_ea/predict.py:164-168,171,184-187 ; I_ea/loss_fn.py:44-47
+ *   si_mel_frontend      <- 22.05 kHz masking + normalize*0.95 + get_mel
+ *                           I_ea/predict.py:99-106 ; I_ea/dataset/mel_dump.py:40-98
  *   si_hifigan_forward   <- extend_mel + Generator.forward     I_ea/hifi_gan/inference_modified.py:16-19 ;
  *                           I_ea/hifi_gan/models.py:107-123 (called at I_ea/predict.py:189,203)
  *   si_load_weights      <- model.load_state_dict / generator.load_state_dict + remove_weight_norm + ApplyKmeans
@@ -132,6 +134,17 @@ int si_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, const int3
  * stretch = 0 skips extend_mel (mel already at the generator's frame rate; output (B, Tm * hop)). */
 int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch, float* wav_out,
                        void* workspace, size_t workspace_bytes, si_stream_t stream);
+
+/* Log-mel front-end of the vocoder side.  wave22: device fp32 (B, N22), the RAW 22.05 kHz clip.  Per clip the span
+ * [mask_start[b], mask_end[b]) (device int32, samples; both NULL = no masking) is zeroed, the clip is divided by its
+ * max |x| and scaled by 0.95 (normalize != 0; I_ea/predict.py:99-104), then get_mel (I_ea/dataset/mel_dump.py:40-98,
+ * constants :11-20: n_fft = win = 1024, hop 441, reflect pad 312, 80 Slaney bands 0-8 kHz at 22.05 kHz) is applied.
+ * mel_out: device fp32 (B, 80, Tm), Tm = si_mel_frames(N22): the layout si_codebook_splice / si_hifigan_forward take.
+ * Needs no weights.  Workspace: si_mel_workspace_bytes. */
+int si_mel_frames(int n22);                              /* (n22 + 2*312 - 1024) / 441 + 1, <= 0 when too short */
+int si_mel_workspace_bytes(si_ctx* ctx, int B, int N22, size_t* out);
+int si_mel_frontend(si_ctx* ctx, const float* wave22, const int32_t* mask_start, const int32_t* mask_end, int normalize,
+                    int B, int N22, float* mel_out, void* workspace, size_t workspace_bytes, si_stream_t stream);
 
 /* Shape helpers (host arithmetic only). */
 int si_num_frames(const si_ctx* ctx, int N);            /* encoder frames T for N samples, <0 on error */

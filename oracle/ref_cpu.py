@@ -25,6 +25,80 @@ import torch.nn.functional as F
 LRELU_SLOPE = 0.1  # I_ea/hifi_gan/models.py:9
 
 
+# ----------------------------------------------------------------------------- f-1 (mel front-end)
+# Constants of I_ea/dataset/mel_dump.py:11-20.
+N_FFT, NUM_MELS, HOP, WIN, MEL_PAD, SR22, FMIN, FMAX = 1024, 80, 441, 1024, 312, 22050, 0.0, 8000.0
+
+
+def mel_filterbank(sr: int = SR22, n_fft: int = N_FFT, n_mels: int = NUM_MELS, fmin: float = FMIN, fmax: float = FMAX):
+    """`librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax)` as called at I_ea/dataset/mel_dump.py:66 (htk=False,
+    norm='slaney'): triangular filters on the Slaney mel scale, each scaled by 2 / (f[i+2] - f[i]).
+    librosa is absent from this image, so THIS function is pinned only by the published formula and by the
+    known-answer properties in tests/test_oracle_golden.py ("filterbank parity unpinned"); everything else in
+    `mel_spectrogram` below is the reference's own torch calls.  Returns float32 (n_mels, 1 + n_fft // 2)."""
+    import numpy as np
+
+    f_sp, min_log_hz, logstep = 200.0 / 3, 1000.0, math.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, f / f_sp)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.linspace(0.0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    w = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        w[i] = np.maximum(0.0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def mel_spectrogram(y: torch.Tensor) -> torch.Tensor:
+    """`get_mel` = `mel_spectrogram` of I_ea/dataset/mel_dump.py:40-98: y (B, n) in [-1, 1] at 22.05 kHz -> (B, 80, Tm).
+    Same torch calls in the same order (:71-91); `return_complex=True` + view_as_real is the same STFT arithmetic as
+    the script's deprecated `return_complex=False`."""
+    basis = torch.from_numpy(mel_filterbank()).to(y.device)
+    window = torch.hann_window(WIN, device=y.device)                                         # :68
+    y = F.pad(y.unsqueeze(1), (MEL_PAD, MEL_PAD), mode="reflect").squeeze(1)                # :72-73
+    spec = torch.view_as_real(torch.stft(y, N_FFT, hop_length=HOP, win_length=WIN, window=window, center=False,
+                                         pad_mode="reflect", normalized=False, onesided=True, return_complex=True))
+    spec = torch.sqrt(spec.pow(2).sum(-1) + 1e-9)                                            # :89
+    spec = torch.matmul(basis, spec)                                                         # :90
+    return torch.log(torch.clamp(spec, min=1e-5))                                            # :31,91
+
+
+def peak_normalize_095(x):
+    """`librosa.util.normalize(x) * 0.95` (I_ea/predict.py:93,104) on a float32 numpy clip: divide by max |x| (norm=inf;
+    a peak below the dtype's tiny leaves the clip unscaled, librosa's `fill=None` rule), then scale, both in float32."""
+    import numpy as np
+
+    x = np.asarray(x, dtype=np.float32)
+    m = np.max(np.abs(x)) if x.size else np.float32(0)
+    if m < np.finfo(np.float32).tiny:
+        m = np.float32(1.0)
+    return (x / np.float32(m)) * np.float32(0.95)
+
+
+def masked_mel(wave22, mask_start: Optional[Sequence[int]], mask_end: Optional[Sequence[int]], normalize: bool = True) -> torch.Tensor:
+    """I_ea/predict.py:99-106 for a batch: copy, zero [start, end) (22.05 kHz samples), normalise * 0.95, get_mel."""
+    import numpy as np
+
+    clips = []
+    for b, w in enumerate(wave22):
+        m = np.array(w, dtype=np.float32, copy=True)
+        if mask_start is not None:
+            m[int(mask_start[b]):int(mask_end[b])] = 0                                       # :102
+        clips.append(peak_normalize_095(m) if normalize else m)                              # :104
+    return mel_spectrogram(torch.from_numpy(np.stack(clips)))
+
+
 # ----------------------------------------------------------------------------- A0
 def mask_and_normalize(wave: torch.Tensor, mask_start: Sequence[int], mask_len: Sequence[int]) -> torch.Tensor:
     """A0.  Zero samples [start, start+len) of each clip (I_ea/predict.py:132-133), then the HF processor's

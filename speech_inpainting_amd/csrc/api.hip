@@ -78,6 +78,10 @@ struct si_ctx {
     // second stream of the vocoder (si_hifigan_forward runs two halves of a chunk concurrently)
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // constant tables of the mel front-end (built on first use): DFT matrix [Npad][n_fft] = rows cos | -sin, periodic
+    // Hann window, transposed Slaney mel basis with the non-zero bin span of every band
+    char* fe_dev = nullptr;
+    size_t fe_dft = 0, fe_hann = 0, fe_basis = 0, fe_lo = 0, fe_hi = 0;
 };
 
 static char g_create_err[512] = "";
@@ -562,6 +566,7 @@ int si_create(si_ctx** out, int device_id, const si_model_desc* desc) {
 void si_destroy(si_ctx* ctx) {
     if (!ctx) return;
     if (ctx->wdev) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->wdev); }
+    if (ctx->fe_dev) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->fe_dev); }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->aux_stream) { (void)hipStreamDestroy(ctx->aux_stream); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
     delete ctx;
@@ -869,6 +874,140 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
     }
     return SI_OK;
 }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ mel front-end (f-1)
+namespace {
+
+// constants of I_ea/dataset/mel_dump.py:11-20
+constexpr int FE_NFFT = 1024, FE_HOP = 441, FE_PAD = 312, FE_NMEL = 80, FE_SR = 22050, FE_NBIN = FE_NFFT / 2 + 1;
+constexpr double FE_FMIN = 0.0, FE_FMAX = 8000.0;
+constexpr int FE_N = 2 * FE_NBIN;                      // DFT GEMM columns: re | im
+constexpr int FE_LDSPEC = 1028;                        // spec row stride (16-byte aligned rows)
+
+// Slaney mel scale (librosa.filters.mel defaults htk=False, norm='slaney', as called at mel_dump.py:66)
+double hz_to_mel(double f) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+double mel_to_hz(double m) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+size_t fe_round(size_t b) { return (b + 255) / 256 * 256; }
+
+int ensure_frontend(si_ctx* ctx) {
+    if (ctx->fe_dev) return SI_OK;
+    const int npad = si_round_up(FE_N, si_pick_bn(FE_N));
+    ctx->fe_dft = 0;
+    ctx->fe_hann = ctx->fe_dft + fe_round((size_t)npad * FE_NFFT * 4);
+    ctx->fe_basis = ctx->fe_hann + fe_round((size_t)FE_NFFT * 4);
+    ctx->fe_lo = ctx->fe_basis + fe_round((size_t)FE_NBIN * FE_NMEL * 4);
+    ctx->fe_hi = ctx->fe_lo + fe_round((size_t)FE_NMEL * 4);
+    const size_t total = ctx->fe_hi + fe_round((size_t)FE_NMEL * 4);
+    std::vector<char> host(total, 0);
+    float* dft = reinterpret_cast<float*>(host.data() + ctx->fe_dft);
+    float* hann = reinterpret_cast<float*>(host.data() + ctx->fe_hann);
+    float* basis_t = reinterpret_cast<float*>(host.data() + ctx->fe_basis);
+    int32_t* lo = reinterpret_cast<int32_t*>(host.data() + ctx->fe_lo);
+    int32_t* hi = reinterpret_cast<int32_t*>(host.data() + ctx->fe_hi);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int k = 0; k < FE_NFFT; ++k) hann[k] = (float)(0.5 - 0.5 * std::cos(two_pi * k / FE_NFFT));   // torch.hann_window (periodic)
+    for (int n = 0; n < FE_NBIN; ++n)
+        for (int k = 0; k < FE_NFFT; ++k) {
+            const double a = two_pi * ((long)n * k % FE_NFFT) / FE_NFFT;   // exact argument reduction
+            dft[(size_t)n * FE_NFFT + k] = (float)std::cos(a);
+            dft[(size_t)(FE_NBIN + n) * FE_NFFT + k] = (float)-std::sin(a);
+        }
+    // triangular filters on the Slaney scale, area-normalised
+    std::vector<double> mel_f(FE_NMEL + 2);
+    const double m0 = hz_to_mel(FE_FMIN), m1 = hz_to_mel(FE_FMAX);
+    for (int i = 0; i < FE_NMEL + 2; ++i) mel_f[i] = mel_to_hz(m0 + (m1 - m0) * i / (FE_NMEL + 1));
+    for (int i = 0; i < FE_NMEL; ++i) {
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        int first = FE_NBIN, last = -1;
+        for (int f = 0; f < FE_NBIN; ++f) {
+            const double hz = (double)FE_SR / 2.0 * f / (FE_NBIN - 1);
+            const double lower = (hz - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
+            const double upper = (mel_f[i + 2] - hz) / (mel_f[i + 2] - mel_f[i + 1]);
+            const double w = std::max(0.0, std::min(lower, upper)) * enorm;
+            const float wf32 = (float)w;
+            basis_t[(size_t)f * FE_NMEL + i] = wf32;
+            if (wf32 != 0.f) { first = std::min(first, f); last = f; }
+        }
+        lo[i] = last < 0 ? 0 : first;
+        hi[i] = last < 0 ? 0 : last + 1;
+    }
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    char* dev = nullptr;
+    SI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dev), total));
+    hipError_t e = hipMemcpy(dev, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(dev); return si_fail_hip(ctx, e, "front-end table upload", __FILE__, __LINE__); }
+    ctx->fe_dev = dev;
+    return SI_OK;
+}
+
+size_t mel_ws_bytes(int B, int N22) {
+    const long Tm = (N22 + 2 * FE_PAD - FE_NFFT) / FE_HOP + 1;
+    if (Tm < 1) return 0;
+    return fe_round((size_t)B * 4) + fe_round((size_t)B * Tm * FE_NFFT * 4) + fe_round((size_t)B * Tm * FE_LDSPEC * 4) + 256;
+}
+
+}  // namespace
+
+extern "C" {
+
+int si_mel_frames(int n22) { return n22 + 2 * FE_PAD < FE_NFFT ? 0 : (n22 + 2 * FE_PAD - FE_NFFT) / FE_HOP + 1; }
+
+int si_mel_workspace_bytes(si_ctx* ctx, int B, int N22, size_t* out) {
+    if (!ctx || !out || B <= 0 || si_mel_frames(N22) < 1) return si_fail(ctx, SI_EINVAL, "si_mel_workspace_bytes: bad argument");
+    *out = mel_ws_bytes(B, N22);
+    return SI_OK;
+}
+
+int si_mel_frontend(si_ctx* ctx, const float* wave22, const int32_t* mask_start, const int32_t* mask_end, int normalize, int B,
+                    int N22, float* mel_out, void* workspace, size_t workspace_bytes, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!wave22 || !mel_out || !workspace || B <= 0) return si_fail(ctx, SI_EINVAL, "si_mel_frontend: NULL / empty argument");
+    if ((mask_start == nullptr) != (mask_end == nullptr))
+        return si_fail(ctx, SI_EINVAL, "si_mel_frontend: mask_start and mask_end must both be given or both be NULL");
+    const int Tm = si_mel_frames(N22);
+    if (Tm < 1 || N22 <= FE_PAD) return si_fail(ctx, SI_EINVAL, "clip of %d samples is too short for the %d-sample reflect pad / %d-point STFT", N22, FE_PAD, FE_NFFT);
+    if (workspace_bytes < mel_ws_bytes(B, N22))
+        return si_fail(ctx, SI_ENOMEM, "workspace of %zu bytes < %zu needed for B=%d N22=%d", workspace_bytes, mel_ws_bytes(B, N22), B, N22);
+    int rc = ensure_frontend(ctx);
+    if (rc) return rc;
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carver W{static_cast<char*>(workspace), workspace_bytes};
+    float* peak = W.floats((size_t)B);
+    float* frames = W.floats((size_t)B * Tm * FE_NFFT);
+    float* spec = W.floats((size_t)B * Tm * FE_LDSPEC);
+    if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: mel workspace carve exceeded its own estimate");
+    const float* hann = reinterpret_cast<const float*>(ctx->fe_dev + ctx->fe_hann);
+    if (normalize && (rc = si_launch_wave_peak(ctx, wave22, mask_start, mask_end, B, N22, peak, st))) return rc;
+    if ((rc = si_launch_mel_frames(ctx, wave22, mask_start, mask_end, peak, hann, B, N22, Tm, FE_HOP, FE_PAD, FE_NFFT, normalize, frames, st)))
+        return rc;
+    if ((rc = si_tap(ctx, "mel_frames", frames, (long)B * Tm * FE_NFFT, st))) return rc;
+    // STFT as one exact-fp32 GEMM: (B*Tm, 1024) x (1024, 1026)
+    TapGemmParams p{};
+    p.w = ctx->fe_dev + ctx->fe_dft; p.w_lo = nullptr; p.bias = nullptr; p.res = nullptr;
+    p.x = frames; p.out = spec;
+    p.nseg = 1; p.Lin = B * Tm; p.M = B * Tm; p.ldx = FE_NFFT; p.x_seg_stride = 0;
+    p.Cin = FE_NFFT; p.N = FE_N; p.Npad = si_round_up(FE_N, si_pick_bn(FE_N)); p.ntaps = 1; p.stride = 1; p.dil = 1; p.pad = 0; p.groups = 1;
+    p.ldo = FE_LDSPEC; p.o_seg_stride = 0; p.ooff = 0; p.olimit = (long)B * Tm * FE_LDSPEC;
+    p.pro_slope = 1.f; p.act = SI_ACT_NONE; p.alpha = 1.f; p.accumulate = 0;
+    if ((rc = si_launch_tapgemm(ctx, SI_MATH_F32, p, st))) return rc;
+    return si_launch_mel_project(ctx, spec, FE_LDSPEC, FE_NBIN, reinterpret_cast<const float*>(ctx->fe_dev + ctx->fe_basis),
+                                 reinterpret_cast<const int32_t*>(ctx->fe_dev + ctx->fe_lo),
+                                 reinterpret_cast<const int32_t*>(ctx->fe_dev + ctx->fe_hi), FE_NMEL, B, Tm, mel_out, st);
+}
+
+}  // extern "C"
+
+extern "C" {
 
 int si_profile_start(si_ctx* ctx, int max_launches) {
     if (!ctx || max_launches <= 0) return si_fail(ctx, SI_EINVAL, "si_profile_start: bad argument");

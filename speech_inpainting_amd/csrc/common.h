@@ -97,6 +97,19 @@ int si_launch_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, int
                               const float* cb_rnorm /*K*/, int K, float* mel, int Tm, int64_t* labels, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
+// mel front-end kernels (frontend_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+int si_launch_wave_peak(si_ctx* ctx, const float* wav, const int32_t* ms, const int32_t* me, int B, int N, float* peak,
+                        hipStream_t st);
+// mask -> normalise*0.95 -> reflect-pad -> Hann window, as the (B*Tm, nfft) frame matrix
+int si_launch_mel_frames(si_ctx* ctx, const float* wav, const int32_t* ms, const int32_t* me, const float* peak,
+                         const float* hann, int B, int N, int Tm, int hop, int pad, int nfft, int normalize, float* frames,
+                         hipStream_t st);
+// spec rows [re | im] -> sqrt(re^2+im^2+1e-9) -> banded mel basis -> log(clamp 1e-5) -> mel (B, nmel, Tm)
+int si_launch_mel_project(si_ctx* ctx, const float* spec, int ld_spec, int nbin, const float* basis_t, const int32_t* lo,
+                          const int32_t* hi, int nmel, int B, int Tm, float* mel, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------
 // vocoder kernels (vocoder_kernels.hip)
 // ------------------------------------------------------------------------------------------------
 // mel (B, D, Tm) channels-first -> (B, Tout, ldo) channels-last, time-stretched (stretch=1) or copied;

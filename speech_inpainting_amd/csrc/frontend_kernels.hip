@@ -1,0 +1,117 @@
+// frontend_kernels.hip -- log-mel front-end of the vocoder side, gfx950.
+//
+// Replaces, on the predict path, I_ea/predict.py:99-106 (zero the masked span of the 22.05 kHz clip,
+// `librosa.util.normalize(x) * 0.95`) and I_ea/dataset/mel_dump.py:40-98 (`get_mel`: reflect-pad 312, STFT with
+// n_fft = win = 1024, hop 441, periodic Hann, center=False; sqrt(re^2 + im^2 + 1e-9); 80-band Slaney mel basis;
+// log(clamp(., 1e-5))).
+//
+// Shape of the work: per clip 200 frames x 1024 samples x 1026 DFT outputs = 0.2 GMAC, 0.2 % of the path, so the DFT
+// is simply one exact-fp32 tap-GEMM launch over an explicit frame matrix (the frames of a 32-clip batch are 26 MB:
+// writing them once costs microseconds and keeps every GEMM row 16-byte aligned; hop 441 is odd).  The three kernels
+// here are the HBM/latency-side pieces around that GEMM:
+//   wave_peak_kernel    max |x| of the masked clip                                   (one pass over 353 KB / clip)
+//   mel_frames_kernel   mask -> normalise -> reflect-pad -> window, written as the (B*Tm, 1024) frame matrix
+//   mel_project_kernel  magnitude, banded mel projection (only the non-zero span of each triangle), log, transposed
+//                       store into the reference's (B, 80, Tm) layout
+#include "common.h"
+
+__global__ __launch_bounds__(1024) void wave_peak_kernel(const float* __restrict__ wav, const int32_t* __restrict__ ms,
+                                                         const int32_t* __restrict__ me, int N, float* __restrict__ peak) {
+    const int b = blockIdx.x;
+    const float* x = wav + (size_t)b * N;
+    const int s = ms ? ms[b] : 0, e = ms ? me[b] : 0;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        const float v = (i >= s && i < e) ? 0.f : fabsf(x[i]);
+        m = fmaxf(m, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float part[16];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, part[w]);
+        peak[b] = m;
+    }
+}
+
+// grid (Tm, B), 256 threads: thread t writes samples 4t .. 4t+3 of its frame.
+__global__ __launch_bounds__(256) void mel_frames_kernel(const float* __restrict__ wav, const int32_t* __restrict__ ms,
+                                                         const int32_t* __restrict__ me, const float* __restrict__ peak,
+                                                         const float* __restrict__ hann, int N, int Tm, int hop, int pad,
+                                                         int nfft, int normalize, float* __restrict__ frames) {
+    const int m = blockIdx.x, b = blockIdx.y;
+    const float* x = wav + (size_t)b * N;
+    const int s = ms ? ms[b] : 0, e = ms ? me[b] : 0;
+    // librosa.util.normalize: divide by max |x|; a peak below the smallest normal float leaves the clip unscaled
+    const float pk = normalize ? peak[b] : 1.f;
+    const float div = pk < 1.17549435e-38f ? 1.f : pk;
+    float* dst = frames + ((size_t)b * Tm + m) * nfft;
+    for (int k = threadIdx.x * 4; k < nfft; k += 1024) {
+        float4 o;
+        float* op = reinterpret_cast<float*>(&o);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int j = m * hop + k + u - pad;                      // position in the un-padded clip
+            if (j < 0) j = -j;                                  // reflect (no edge repeat), mel_dump.py:72
+            if (j >= N) j = 2 * (N - 1) - j;
+            float v = (j >= s && j < e) ? 0.f : x[j];
+            if (normalize) v = (v / div) * 0.95f;               // predict.py:104, in the script's operation order
+            op[u] = v * hann[k + u];
+        }
+        *reinterpret_cast<float4*>(dst + k) = o;
+    }
+}
+
+// One workgroup per frame.  spec row = [re(0..nbin-1) | im(0..nbin-1)] as the DFT GEMM wrote it.
+// basis_t is the mel basis transposed to (nbin, nmel); band i is non-zero on bins [lo[i], hi[i]).
+__global__ __launch_bounds__(128) void mel_project_kernel(const float* __restrict__ spec, int ld_spec, int nbin,
+                                                          const float* __restrict__ basis_t, const int32_t* __restrict__ lo,
+                                                          const int32_t* __restrict__ hi, int nmel, int Tm,
+                                                          float* __restrict__ mel) {
+    extern __shared__ float mag[];
+    const long row = blockIdx.x;
+    const float* sp = spec + row * ld_spec;
+    for (int f = threadIdx.x; f < nbin; f += blockDim.x) {
+        const float re = sp[f], im = sp[nbin + f];
+        mag[f] = sqrtf(re * re + im * im + 1e-9f);              // mel_dump.py:89
+    }
+    __syncthreads();
+    const int b = (int)(row / Tm), m = (int)(row % Tm);
+    for (int i = threadIdx.x; i < nmel; i += blockDim.x) {
+        float acc = 0.f;
+        for (int f = lo[i]; f < hi[i]; ++f) acc = fmaf(basis_t[(size_t)f * nmel + i], mag[f], acc);
+        mel[((size_t)b * nmel + i) * Tm + m] = logf(fmaxf(acc, 1e-5f));   // mel_dump.py:31,91
+    }
+}
+
+int si_launch_wave_peak(si_ctx* ctx, const float* wav, const int32_t* ms, const int32_t* me, int B, int N, float* peak,
+                        hipStream_t st) {
+    si_prof_begin(ctx, "wave_peak", (double)B * N, (double)B * N * 4, st);
+    wave_peak_kernel<<<B, 1024, 0, st>>>(wav, ms, me, N, peak);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
+int si_launch_mel_frames(si_ctx* ctx, const float* wav, const int32_t* ms, const int32_t* me, const float* peak,
+                         const float* hann, int B, int N, int Tm, int hop, int pad, int nfft, int normalize, float* frames,
+                         hipStream_t st) {
+    if (nfft % 4) return si_fail(ctx, SI_EINVAL, "mel_frames: n_fft %d is not a multiple of 4", nfft);
+    if (N <= pad) return si_fail(ctx, SI_EINVAL, "mel_frames: clip of %d samples is not longer than the reflect pad %d", N, pad);
+    si_prof_begin(ctx, "mel_frames", 3.0 * B * Tm * nfft, (double)B * N * 4 + (double)B * Tm * nfft * 4, st);
+    mel_frames_kernel<<<dim3(Tm, B), 256, 0, st>>>(wav, ms, me, peak, hann, N, Tm, hop, pad, nfft, normalize, frames);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
+int si_launch_mel_project(si_ctx* ctx, const float* spec, int ld_spec, int nbin, const float* basis_t, const int32_t* lo,
+                          const int32_t* hi, int nmel, int B, int Tm, float* mel, hipStream_t st) {
+    const long rows = (long)B * Tm;
+    si_prof_begin(ctx, "mel_project", (double)rows * (4.0 * nbin + 2.0 * nbin * 2), (double)rows * (2.0 * nbin + nmel) * 4, st);
+    mel_project_kernel<<<(unsigned)rows, 128, (size_t)nbin * sizeof(float), st>>>(spec, ld_spec, nbin, basis_t, lo, hi, nmel, Tm, mel);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}

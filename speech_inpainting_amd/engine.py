@@ -62,6 +62,16 @@ class InpaintingEngine:
     def vocode(self, mel: torch.Tensor, stretch: bool = True) -> torch.Tensor:
         return self.ctx.hifigan_forward(mel, stretch)
 
+    def mel(self, wave22: torch.Tensor, mask_start: Optional[torch.Tensor] = None, mask_end: Optional[torch.Tensor] = None,
+            normalize: bool = True) -> torch.Tensor:
+        """Vocoder-side front-end (I_ea/predict.py:99-106): zero [mask_start, mask_end) of each raw 22.05 kHz clip,
+        peak-normalise * 0.95, log-mel -> (B, 80, Tm)."""
+        return self.ctx.mel_frontend(wave22, mask_start, mask_end, normalize)
+
+    def get_mel(self, x: torch.Tensor) -> torch.Tensor:
+        """`get_mel(x)` of I_ea/dataset/mel_dump.py:96-98: x (B, n) already normalised -> (B, 80, Tm) log-mel."""
+        return self.ctx.mel_frontend(x, None, None, normalize=False)
+
     def predict_batch(self, wave16: torch.Tensor, mel: torch.Tensor, frame_pos: torch.Tensor, frame_len: int,
                       blind: bool = False, mask_start: Optional[torch.Tensor] = None,
                       mask_len: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:

@@ -22,7 +22,8 @@ SI_MAX_CONV, SI_MAX_UPS, SI_MAX_RB, SI_MAX_DIL = 8, 8, 4, 4
 
 EXPORTS = ["si_version", "si_create", "si_destroy", "si_last_error", "si_load_weights", "si_alloc_weights",
            "si_weights_device_ptr", "si_workspace_bytes", "si_hubert_forward", "si_codebook_splice",
-           "si_hifigan_forward", "si_num_frames", "si_vocoder_samples", "si_profile_start", "si_profile_stop",
+           "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
+           "si_vocoder_samples", "si_profile_start", "si_profile_stop",
            "si_debug_capture", "si_debug_size"]
 
 
@@ -121,6 +122,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.si_hubert_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_codebook_splice.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp]
     lib.si_hifigan_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, sz, vp]
+    lib.si_mel_frames.argtypes = [i32]
+    lib.si_mel_workspace_bytes.argtypes = [vp, i32, i32, C.POINTER(sz)]
+    lib.si_mel_frontend.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_num_frames.argtypes = [vp, i32]
     lib.si_vocoder_samples.argtypes = [vp, i32, i32]
     lib.si_debug_capture.argtypes = [vp, C.c_char_p, vp, C.c_long]
@@ -253,6 +257,27 @@ class NativeContext:
         ws = self.workspace(B, 0, Tm)
         self._check(self.lib.si_hifigan_forward(self._h, _ptr(mel), B, Tm, int(stretch), _ptr(out), _ptr(ws), ws.numel(),
                                                 self._stream()), "si_hifigan_forward")
+        return out
+
+    def mel_frontend(self, wave22: torch.Tensor, mask_start: Optional[torch.Tensor] = None,
+                     mask_end: Optional[torch.Tensor] = None, normalize: bool = True) -> torch.Tensor:
+        """(B, N22) raw 22.05 kHz clips -> (B, 80, Tm) log-mel; the span [mask_start, mask_end) of each clip is zeroed first."""
+        assert wave22.is_cuda and wave22.dtype == torch.float32 and wave22.dim() == 2 and wave22.is_contiguous()
+        B, N = wave22.shape
+        Tm = int(self.lib.si_mel_frames(N))
+        if Tm < 1:
+            raise ValueError(f"clip of {N} samples is too short for the mel front-end")
+        assert (mask_start is None) == (mask_end is None)
+        for m in (mask_start, mask_end):
+            assert m is None or (m.is_cuda and m.dtype == torch.int32 and m.numel() == B and m.is_contiguous())
+        need = C.c_size_t(0)
+        self._check(self.lib.si_mel_workspace_bytes(self._h, B, N, C.byref(need)), "si_mel_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        out = torch.empty(B, 80, Tm, dtype=torch.float32, device=self.device)
+        self._check(self.lib.si_mel_frontend(self._h, _ptr(wave22), _ptr(mask_start), _ptr(mask_end), int(normalize), B, N,
+                                             _ptr(out), _ptr(self._ws), self._ws.numel(), self._stream()), "si_mel_frontend")
         return out
 
     def capture(self, names, capacity: int = 0):

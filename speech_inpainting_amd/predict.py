@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import os
 import sys
-from typing import Dict, Optional, Sequence
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -45,22 +45,26 @@ def build_engine(cfg: PredictConfig, device: Optional[torch.device] = None, enco
 
 
 def predict_clips(engine: InpaintingEngine, waves16: Sequence[np.ndarray], waves22: Sequence[np.ndarray],
-                  mask_pos: Sequence[int], mask_frames: int, blind: bool = False) -> Dict[str, torch.Tensor]:
+                  mask_pos: Sequence[int], mask_frames: int, blind: bool = False,
+                  mask22: Optional[Sequence[Tuple[int, int]]] = None) -> Dict[str, torch.Tensor]:
     """Batch form of I_ea/predict.py:97-207 for clips of EQUAL length.
-    waves16 / waves22: the same clips at 16 kHz / 22.05 kHz (float32, un-normalised), mask_pos: first masked 20 ms frame."""
+    waves16 / waves22: the same clips at 16 kHz / 22.05 kHz (float32, un-normalised), mask_pos: first masked 20 ms frame.
+    mask22: per-clip [start, end) of the span zeroed on the 22.05 kHz side (predict.py:99-102: the 16 kHz sample
+    positions of the YAML times scaled by 22050 // 16000); default = the frame span."""
     dev = engine.device
     n16, n22 = len(waves16[0]), len(waves22[0])
     if any(len(w) != n16 for w in waves16) or any(len(w) != n22 for w in waves22):
         raise ValueError("clips in one batch must have equal length (group by exact length; HuBERT-base's GroupNorm "
                          "is not padding-invariant)")
-    masked22 = []
-    for w, p in zip(waves22, mask_pos):
-        m = np.array(w, dtype=np.float32, copy=True)
-        if not blind:
-            s16, e16 = p * 320, (p + mask_frames) * 320
-            m[s16 * 22050 // 16000: e16 * 22050 // 16000] = 0                      # predict.py:99-103
-        masked22.append(audio.peak_normalize(m))                                   # predict.py:104
-    mel = audio.mel_spectrogram(torch.from_numpy(np.stack(masked22)).to(dev)).contiguous()
+    wave22 = torch.from_numpy(np.stack([np.asarray(w, dtype=np.float32) for w in waves22])).to(dev)
+    if blind:
+        mel = engine.mel(wave22)                                                    # nothing zeroed; predict.py:104-106
+    else:
+        if mask22 is None:
+            mask22 = [(p * 320 * 22050 // 16000, (p + mask_frames) * 320 * 22050 // 16000) for p in mask_pos]
+        s22 = torch.tensor([min(max(int(a), 0), n22) for a, _ in mask22], dtype=torch.int32, device=dev)
+        e22 = torch.tensor([min(max(int(b), 0), n22) for _, b in mask22], dtype=torch.int32, device=dev)
+        mel = engine.mel(wave22, s22, e22)                                          # predict.py:99-106 on the GPU
     wave = torch.from_numpy(np.stack([np.asarray(w, dtype=np.float32) for w in waves16])).to(dev)
     pos = torch.tensor(list(mask_pos), dtype=torch.int32, device=dev)
     out = engine.predict_batch(wave, mel, pos, mask_frames, blind=blind)
@@ -85,7 +89,8 @@ def main(argv=None) -> int:
     masked_16[pos * 320 + 80:(pos + lm) * 320 + 79 - 80] = 0                       # predict.py:133
     audio.write_wav(os.path.join(save_dir, "masked.wav"), masked_16, 16000)
 
-    out = predict_clips(engine, [wave_16], [wave_22], [pos], lm)
+    span22 = (cfg.start_sample * 22050 // 16000, cfg.end_sample * 22050 // 16000)   # predict.py:99-100
+    out = predict_clips(engine, [wave_16], [wave_22], [pos], lm, mask22=[span22])
     # hifi_masked.wav: the vocoder on the masked mel alone (predict.py:123-128)
     hm = engine.vocode(out["mel_masked"], stretch=True)
     audio.write_wav(os.path.join(save_dir, "hifi_masked.wav"), audio.to_int16_pcm(hm[0]), 22050)

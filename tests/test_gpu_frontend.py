@@ -1,0 +1,91 @@
+"""GPU parity of the mel front-end: si_mel_frontend through the C ABI vs the oracle's
+restatement of I_ea/predict.py:99-106 + I_ea/dataset/mel_dump.py:40-98.
+
+Tolerance: the reference computes the STFT with an fp32 FFT, the HIP path as an exact-fp32 DFT GEMM; both carry
+~1e-6 relative rounding on the magnitudes, and log() turns a relative error into an absolute one, so the gate is an
+absolute 2e-4 on the log-mel (values span [-11.5, +3]); typical error is ~1e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from speech_inpainting_amd import synth
+from speech_inpainting_amd.arch import HubertArch, VocoderArch, mel_frames
+
+pytestmark = pytest.mark.gpu
+
+MEL_ATOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from speech_inpainting_amd import native
+    c = native.NativeContext(native.make_desc(HubertArch.tiny(), VocoderArch.tiny(), 10), torch.device("cuda:0"))
+    yield c
+    c.close()
+
+
+def _clips(B, n, seed):
+    return synth.synth_wave(B, n, seed, sr=22050).numpy()
+
+
+@pytest.mark.parametrize("n22", [88200, 66150, 22063, 220500])
+def test_masked_mel_matches_oracle(ctx, n22):
+    B = 3
+    w = _clips(B, n22, 11) * np.array([[0.3], [1.7], [0.05]], dtype=np.float32)       # peaks below and above 1
+    starts = [n22 // 3, 0, n22 - 2000]
+    ends = [n22 // 3 + 4410, 1500, n22]                                               # interior, at the head, at the tail
+    ref = R.masked_mel(w, starts, ends)
+    dev = torch.device("cuda:0")
+    got = ctx.mel_frontend(torch.from_numpy(w).to(dev), torch.tensor(starts, dtype=torch.int32, device=dev),
+                           torch.tensor(ends, dtype=torch.int32, device=dev))
+    assert got.shape == ref.shape == (B, 80, mel_frames(n22))
+    err = (got.cpu() - ref).abs()
+    assert float(err.max()) <= MEL_ATOL, float(err.max())
+    assert float(err.mean()) <= 2e-5, float(err.mean())
+
+
+def test_get_mel_without_mask_or_normalisation(ctx):
+    w = _clips(2, 44100, 5) * 0.4
+    ref = R.mel_spectrogram(torch.from_numpy(w))
+    got = ctx.mel_frontend(torch.from_numpy(w).cuda(), None, None, normalize=False)
+    assert float((got.cpu() - ref).abs().max()) <= MEL_ATOL
+    # normalised, no mask (the `orig` figure of predict.py:92-95)
+    ref2 = R.masked_mel(w, None, None)
+    got2 = ctx.mel_frontend(torch.from_numpy(w).cuda())
+    assert float((got2.cpu() - ref2).abs().max()) <= MEL_ATOL
+
+
+def test_silent_and_fully_masked_clips(ctx):
+    n = 30000
+    w = _clips(2, n, 3)
+    w[0] = 0.0
+    s, e = torch.tensor([0, 0], dtype=torch.int32).cuda(), torch.tensor([0, n], dtype=torch.int32).cuda()
+    got = ctx.mel_frontend(torch.from_numpy(w).cuda(), s, e).cpu()
+    ref = R.masked_mel(w, [0, 0], [0, n])
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= 1e-5          # sqrt(1e-9) floor through the mel basis
+    assert torch.equal(got[0], got[1])
+
+
+def test_peak_normalisation_makes_gain_irrelevant_at_full_batch(ctx):
+    """Size-independent property on the bench-size batch: power-of-two gains are exact in fp32, so the normalised
+    mel of 4x and x/8 must be bit-identical to that of x."""
+    B, n = 32, 88200
+    w = torch.from_numpy(_clips(B, n, 17)).cuda()
+    s = torch.full((B,), 40000, dtype=torch.int32, device="cuda")
+    e = s + 4410
+    a = ctx.mel_frontend(w, s, e)
+    b = ctx.mel_frontend(w * 4.0, s, e)
+    c = ctx.mel_frontend(w * 0.125, s, e)
+    assert torch.equal(a, b) and torch.equal(a, c)
+    # and the masked span shows up as the floor value in the frames that lie wholly inside it
+    inside = a[:, :, (40000 + 312) // 441 + 3:(44410 + 312 - 1024) // 441 - 1]
+    assert inside.numel() > 0 and float(inside.max()) < -9.0
+
+
+def test_too_short_clip_is_refused(ctx):
+    from speech_inpainting_amd.native import NativeError
+    with pytest.raises((NativeError, ValueError)):
+        ctx.mel_frontend(torch.zeros(1, 300, device="cuda"))

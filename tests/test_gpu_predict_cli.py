@@ -53,19 +53,18 @@ km_model: {{n_clusters: 100, LJSpeech: {{path2centroids: '{tmp_path}/kmeans/', k
     sr, pcm = wavfile.read(out / "inpainted.wav")
     assert sr == 22050 and pcm.dtype == np.int16
 
-    # same glue, oracle in place of the engine: int16 samples may differ by 1 LSB at most (truncation of a 1e-7 error)
+    # same glue, oracle in place of the engine (mel front-end included): int16 samples differ by a couple of LSB at
+    # most (the HIP mel is within ~1e-5 of torch's FFT-based one; 1 LSB = 3e-5)
     w16 = audio.load_audio(str(tmp_path / "wavs" / "clip.wav"), 16000)
     w22r = audio.load_audio(str(tmp_path / "wavs" / "clip.wav"), 22050)
     from speech_inpainting_amd.config import load_predict_config
     cfg = load_predict_config(str(tmp_path / "predict.yaml"))
     pos, lm = cfg.mask_pos, cfg.mask_frames
-    m22 = w22r.copy()
-    m22[pos * 320 * 22050 // 16000:(pos + lm) * 320 * 22050 // 16000] = 0
-    mel = audio.mel_spectrogram(torch.from_numpy(audio.peak_normalize(m22))[None])
+    mel = R.masked_mel([w22r], [cfg.start_sample * 22050 // 16000], [cfg.end_sample * 22050 // 16000])   # predict.py:99-106
     ref = R.predict_batch(hsd, harch, gsd, varch, cb, torch.from_numpy(w16)[None], mel, [pos], lm)
     ref_pcm = audio.to_int16_pcm(ref["wave"][0])
     assert pcm.shape == ref_pcm.shape == (mel.shape[2] * 441 // 256 * 256,) or pcm.shape == ref_pcm.shape
     diff = np.abs(pcm.astype(np.int32) - ref_pcm.astype(np.int32))
-    assert diff.max() <= 1 and (diff > 0).mean() < 0.01
+    assert diff.max() <= 2 and (diff > 1).mean() < 0.001, (diff.max(), (diff > 0).mean())
     sr16, masked = wavfile.read(out / "masked.wav")
     assert sr16 == 16000 and np.all(masked[pos * 320 + 80:(pos + lm) * 320 - 1] == 0)

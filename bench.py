@@ -59,11 +59,15 @@ def cpu_baseline(batch: int):
     harch, varch = HubertArch.base(), VocoderArch.v1()
     hsd, gsd, cb = synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook()
     Tm = mel_frames(N_SAMPLES * 22050 // 16000)
-    wave, mel = synth.synth_wave(batch, N_SAMPLES), synth.synth_mel(batch, Tm)
+    wave = synth.synth_wave(batch, N_SAMPLES)
+    wave22 = synth.synth_wave(batch, N_SAMPLES * 22050 // 16000, synth.DEFAULT_SEED + 6, sr=22050).numpy()
     pos = synth.synth_mask_frames(batch, harch.num_frames(N_SAMPLES), MASK_FRAMES).tolist()
-    R.predict_batch(hsd, harch, gsd, varch, cb, wave[:1], mel[:1], pos[:1], MASK_FRAMES)      # warm-up
+    s22 = [p * 320 * 22050 // 16000 for p in pos]
+    e22 = [(p + MASK_FRAMES) * 320 * 22050 // 16000 for p in pos]
+    assert R.masked_mel(wave22[:1], s22[:1], e22[:1]).shape[2] == Tm
+    R.predict_batch(hsd, harch, gsd, varch, cb, wave[:1], R.masked_mel(wave22[:1], s22[:1], e22[:1]), pos[:1], MASK_FRAMES)  # warm-up
     t0 = time.perf_counter()
-    R.predict_batch(hsd, harch, gsd, varch, cb, wave, mel, pos, MASK_FRAMES)
+    R.predict_batch(hsd, harch, gsd, varch, cb, wave, R.masked_mel(wave22, s22, e22), pos, MASK_FRAMES)
     dt = time.perf_counter() - t0
     return {"value": round(batch * CLIP_SECONDS / dt, 3), "unit": "x real-time (audio-sec/wall-sec)", "cores": cores, "kind": "port",
             "sample": f"{batch} of the same 4 s clips, one pass, fp32, torch CPU oracle (oracle/ref_cpu.py), {dt:.2f} s wall"}
@@ -147,10 +151,12 @@ def main():
     # this rank's slice of the global utterance list (seeded per global clip index)
     lo, hi = parallel.shard_range(B * world, rank, world)
     wave = synth.synth_wave(hi - lo, N_SAMPLES, synth.DEFAULT_SEED + 3 + lo).to(dev)
-    mel = synth.synth_mel(hi - lo, Tm, 80, synth.DEFAULT_SEED + 4 + lo).to(dev)
+    wave22 = synth.synth_wave(hi - lo, N_SAMPLES * 22050 // 16000, synth.DEFAULT_SEED + 6 + lo, sr=22050).to(dev)
     pos = synth.synth_mask_frames(hi - lo, T, MASK_FRAMES, synth.DEFAULT_SEED + 5 + lo).to(dev)
     mstart = (pos * 320 + 80).to(torch.int32)
     mlen = torch.full_like(pos, MASK_FRAMES * 320 - 81)
+    s22 = (pos * 320 * 22050 // 16000).to(torch.int32)                       # I_ea/predict.py:99-100
+    e22 = ((pos + MASK_FRAMES) * 320 * 22050 // 16000).to(torch.int32)
 
     def run_mode(enc, voc, steps, warmup, events):
         t_load = time.perf_counter()
@@ -160,6 +166,8 @@ def main():
             log(f"[bench] encoder {enc}, vocoder {voc}: setup {time.perf_counter() - t_load:.1f} s; B={B}/GPU x {world} GPU, T={T}, Tm={Tm}")
 
         def step():
+            # raw 16 kHz + 22.05 kHz clips in HBM -> masked log-mel (f-1) -> encoder -> arg-max/splice -> vocoder
+            mel = eng.mel(wave22, s22, e22)
             return eng.predict_batch(wave, mel, pos, MASK_FRAMES, mask_start=mstart, mask_len=mlen)
 
         for _ in range(warmup):
@@ -209,7 +217,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": f"encoder GEMMs: {dtype_txt[a.encoder_dtype]} (attention, head, arg-max in fp32); vocoder: {dtype_txt[a.vocoder_dtype]}",
         "data": "synthetic (seeded clips, random-init weights of the HuBERT-base + HiFi-GAN V1 architecture)",
-        "config": {"workload": "BASELINE configs[1]: batch=32 x 4 s clips per GPU, 200 ms mask, HuBERT-base + HiFi-GAN V1"
+        "config": {"workload": "BASELINE configs[1]: batch=32 x 4 s clips per GPU, 200 ms mask, HuBERT-base + HiFi-GAN V1; step = masked log-mel front-end -> encoder -> arg-max/splice -> vocoder on resident raw clips"
                                + ("" if world == 1 else f", utterance-sharded over {world} GPUs (configs[2] at 8)"),
                    "global_batch": int(clips), "clip_samples": N_SAMPLES, "mask_frames": MASK_FRAMES,
                    "parallelism": f"utterance-sharded x{world}", "output_rms": round(main_run["rms"], 4)},

@@ -57,10 +57,9 @@ static inline int si_pick_bn(int N) { return N >= 128 ? 128 : (N > 32 ? 64 : 32)
 static inline int si_round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t st);
-// wave-specialised form; returns 1 when the shape is not covered (caller falls back to the unified kernel)
-int si_launch_tapgemm_ws(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t st);
-// persistent cross-tile-pipelined form for convolutions (tapgemm_p.hip); same return convention
-int si_launch_tapgemm_p(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t st);
+// ping-pong form (tapgemm_pp.hip): the two waves of a SIMD alternate MFMA and staging phases.
+// Returns SI_OK when launched, negative on error, 1 when the shape is not covered (caller uses the unified kernel).
+int si_launch_tapgemm_pp(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // encoder kernels (encoder_kernels.hip)

@@ -544,18 +544,11 @@ int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t
     if ((long)p.M * p.ldo + p.ooff < p.olimit)
         return si_fail(ctx, SI_EINVAL, "tapgemm: olimit=%ld must not exceed M*ldo+ooff=%ld (rows >= M are masked by the range check)",
                        p.olimit, (long)p.M * p.ldo + p.ooff);
-    // wave-specialised producer/consumer form (tapgemm_ws.hip): measured slower than this kernel on every shape of the
-    // path (one workgroup per CU exposes its prologue/epilogue); kept selectable with SI_TG_WS=1 for experiments
-    static const int ws_mode = getenv("SI_TG_WS") ? atoi(getenv("SI_TG_WS")) : 0;
-    if (ws_mode) {
-        const int rc = si_launch_tapgemm_ws(ctx, math, p, st);
-        if (rc <= 0) return rc;
-    }
-    // SI_TG_PERSIST=1: persistent cross-tile-pipelined form (tapgemm_p.hip).  Measured slower than the per-tile grid
-    // (bf16x3 256x128w8 15.3 vs 14.7 ms/step; the 256x64 / 256x32 variants spill), so it is opt-in.
-    static const int persist = getenv("SI_TG_PERSIST") ? atoi(getenv("SI_TG_PERSIST")) : 0;
-    if (persist) {
-        const int rc = si_launch_tapgemm_p(ctx, math, p, st);
+    // SI_TG_PP=1: ping-pong form (tapgemm_pp.hip): the two waves of a SIMD alternate MFMA and staging phases.
+    // Parity-green; measured 5-7 % slower than this kernel's lockstep 8-wave tile (bf16x3 14.9 vs 14.0 ms/step), opt-in.
+    static const int pingpong = getenv("SI_TG_PP") ? atoi(getenv("SI_TG_PP")) : 0;
+    if (pingpong) {
+        const int rc = si_launch_tapgemm_pp(ctx, math, p, st);
         if (rc <= 0) return rc;
     }
     const bool k32 = (p.Cin % 32 == 0);

@@ -23,3 +23,17 @@ for fam, label in enumerate(("N-tile 128 (C>=128 stages, ups, conv_pre)", "N-til
     print(f"-- {label}: {v[7]} waves, {v[6] / v[7]:.0f} cycles per wave")
     for n, x in zip(names[:6], v[:6]):
         print(f"   {n:22s} {100.0 * x / v[6]:6.1f} %   {x / v[7]:10.0f} cycles/wave")
+
+if hasattr(lib, "si_debug_stamps_pp"):
+    b2 = (ctypes.c_ulonglong * 16)()
+    lib.si_debug_stamps_pp(b2, 1)
+    eng.vocode(mel); torch.cuda.synchronize()
+    lib.si_debug_stamps_pp(b2, 0)
+    pn = ["compute phases", "stage phases", "barrier after compute", "barrier after stage", "prologue", "epilogue"]
+    for grp in (0, 1):
+        v = b2[grp * 8:(grp + 1) * 8]
+        if not v[7]:
+            continue
+        print(f"-- ping-pong kernel, wave group {grp}: {v[7]} waves, {v[6] / v[7]:.0f} cycles per wave")
+        for n, x in zip(pn, v[:6]):
+            print(f"   {n:22s} {100.0 * x / v[6]:6.1f} %   {x / v[7]:10.0f} cycles/wave")

@@ -8,6 +8,8 @@
  *                           + the zero-mask + processor normalise in front of it (I_ea/predict.py:132-141)
  *   si_codebook_splice   <- frame gather + LossFunction.cos_sim arg-max + centroid splice
  *                           I_ea/predict.py:164-168,171,184-187 ; I_ea/loss_fn.py:44-47
+ *   si_codebook_metrics  <- LossFunction.cos_sim loss + cos_sim_target_labels (row f-4)
+ *                           I_ea/loss_fn.py:29-62 ; I_ea/predict.py:171-173
  *   si_mel_frontend      <- 22.05 kHz masking + normalize*0.95 + get_mel
  *                           I_ea/predict.py:99-106 ; I_ea/dataset/mel_dump.py:40-98
  *   si_hifigan_forward   <- extend_mel + Generator.forward     I_ea/hifi_gan/inference_modified.py:16-19 ;
@@ -129,6 +131,16 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
  * labels device int64 (B, Lm), may be NULL. */
 int si_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, const int32_t* frame_pos, int Lm,
                        float* mel, int Tm, int64_t* labels, si_stream_t stream);
+
+/* Loss half of the same LossFunction call: `loss, pred = cos_sim(values, labels)` and
+ * `cos_sim_target_labels(pred, labels)` (I_ea/loss_fn.py:29-62, called at I_ea/predict.py:171-173).  feats / frame_pos / Lm
+ * as si_codebook_splice (pass the gathered values with T = Lm and frame_pos = 0 to mirror the call exactly).
+ * target_labels: device int64 (B, Lm).  Outputs (device): loss_terms fp32 (B, Lm) = 1 - cos(v, centred target centroid);
+ * loss fp32 (1) = their sum in a fixed order; pred_labels int64 (B, Lm) or NULL; cos_pred_target fp32 (B, Lm) =
+ * cos(centred predicted centroid, centred target centroid).  A target outside [0, K) gives NaN for that frame. */
+int si_codebook_metrics(si_ctx* ctx, const float* feats, int B, int T, const int32_t* frame_pos, int Lm,
+                        const int64_t* target_labels, float* loss_terms, float* loss, int64_t* pred_labels,
+                        float* cos_pred_target, si_stream_t stream);
 
 /* Vocoder: mel (B, D, Tm) -> time-stretch x441/256 -> generator -> wav_out (B, floor(Tm*441/256) * hop).
  * stretch = 0 skips extend_mel (mel already at the generator's frame rate; output (B, Tm * hop)). */

@@ -271,6 +271,19 @@ def codebook_argmax(values: torch.Tensor, centroids: torch.Tensor) -> torch.Tens
     return torch.argmax(sim, dim=1).view(values.shape[:-1])
 
 
+def cos_sim_loss(values: torch.Tensor, labels: torch.Tensor, centroids: torch.Tensor):
+    """f-4.  `LossFunction.cos_sim` in full (I_ea/loss_fn.py:29-47): loss = -sum(cos(v, centred target) - 1), pred =
+    arg-max labels; plus `cos_sim_target_labels` (:49-62).  values (B, Lm, D), labels (B, Lm) ->
+    (loss scalar, pred (B, Lm), cos_pred_target (B*Lm,))."""
+    _, cc = codebook_tables(centroids)
+    flat = values.reshape(-1, values.shape[-1]).float()
+    tgt = cc[labels.reshape(-1)]
+    loss = -(F.cosine_similarity(flat, tgt) - 1).sum()
+    pred = codebook_argmax(values, centroids)
+    cpt = F.cosine_similarity(cc[pred.reshape(-1)].T, cc[labels.reshape(-1)].T, dim=0)
+    return loss, pred, cpt
+
+
 def splice_centroids(mel: torch.Tensor, labels: torch.Tensor, centroids: torch.Tensor, frame_pos: Sequence[int]) -> torch.Tensor:
     """A13.  mel[b, :, pos:pos+Lm] = (centred[labels] + center_).T (I_ea/predict.py:184-187).  mel (B, D, Tm)."""
     center, cc = codebook_tables(centroids)

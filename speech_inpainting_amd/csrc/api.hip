@@ -746,6 +746,20 @@ int si_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, const int3
                                      wf(ctx, L.cb_rnorm), ctx->d.num_clusters, mel, Tm, labels, static_cast<hipStream_t>(stream));
 }
 
+int si_codebook_metrics(si_ctx* ctx, const float* feats, int B, int T, const int32_t* frame_pos, int Lm,
+                        const int64_t* target_labels, float* loss_terms, float* loss, int64_t* pred_labels, float* cos_pred_target,
+                        si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!ctx->weights_ready) return si_fail(ctx, SI_ESTATE, "si_codebook_metrics before weights were loaded");
+    if (!feats || !frame_pos || !target_labels || !loss_terms || !loss || !cos_pred_target || B <= 0 || Lm <= 0)
+        return si_fail(ctx, SI_EINVAL, "si_codebook_metrics: NULL / empty argument");
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    const Layout& L = ctx->lay;
+    return si_launch_codebook_metrics(ctx, feats, B, T, ctx->d.codebook_dim, frame_pos, Lm, wf(ctx, L.cb_centered), wf(ctx, L.cb_rnorm),
+                                      ctx->d.num_clusters, target_labels, loss_terms, loss, pred_labels, cos_pred_target,
+                                      static_cast<hipStream_t>(stream));
+}
+
 int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch, float* wav_out, void* workspace,
                        size_t workspace_bytes, si_stream_t stream) {
     if (!ctx) return SI_EINVAL;

@@ -95,6 +95,12 @@ int si_launch_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, int
                               const float* cb_centered /*K x D*/, const float* cb_raw /*K x D*/,
                               const float* cb_rnorm /*K*/, int K, float* mel, int Tm, int64_t* labels, hipStream_t st);
 
+// loss half of LossFunction.cos_sim + cos_sim_target_labels (f-4): per-frame terms 1 - cos(v, c_target), their
+// fixed-order sum, arg-max labels and cos(c_pred, c_target)
+int si_launch_codebook_metrics(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,
+                               const float* cb_centered, const float* cb_rnorm, int K, const int64_t* target, float* terms,
+                               float* loss, int64_t* pred, float* cos_pt, hipStream_t st);
+
 // ------------------------------------------------------------------------------------------------
 // mel front-end kernels (frontend_kernels.hip)
 // ------------------------------------------------------------------------------------------------

@@ -487,6 +487,105 @@ __global__ __launch_bounds__(128) void codebook_splice_kernel(const float* __res
     if (pos < Tm && (int)threadIdx.x < D) mel[((long)b * D + threadIdx.x) * Tm + pos] = raw[(long)lab * D + threadIdx.x];
 }
 
+// Loss half of LossFunction.cos_sim + cos_sim_target_labels (I_ea/loss_fn.py:29-62).
+// One workgroup per (clip, masked frame): term = 1 - cos(v, c_target), pred = arg-max_k cos(v, c_k) (same rule as the
+// splice kernel), cpt = cos(c_pred, c_target); all cosines as F.cosine_similarity computes them: both vectors divided
+// by max(norm, 1e-8) first, then the dot product.  A target label outside [0, K) yields NaN in both outputs.
+__device__ __forceinline__ float block_sum_128(float x, float* scratch) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    __syncthreads();                                                 // scratch reuse across calls
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return scratch[0] + scratch[1];
+}
+
+__global__ __launch_bounds__(128) void codebook_metrics_kernel(const float* __restrict__ feats, int T, int D,
+                                                               const int32_t* __restrict__ frame_pos, int Lm,
+                                                               const float* __restrict__ cc, const float* __restrict__ rnorm,
+                                                               int K, const int64_t* __restrict__ target,
+                                                               float* __restrict__ terms, int64_t* __restrict__ pred,
+                                                               float* __restrict__ cos_pt) {
+    __shared__ float v[128];
+    __shared__ float red[2];
+    __shared__ float bs[2];
+    __shared__ int bi[2];
+    const int b = blockIdx.y, j = blockIdx.x;
+    const int pos = frame_pos[b] + j;
+    const long o = (long)b * Lm + j;
+    const long y = target[o];
+    const float nanv = __builtin_nanf("");
+    if (pos < 0 || pos >= T || y < 0 || y >= K) {                    // uniform per block
+        if (threadIdx.x == 0) { terms[o] = nanv; cos_pt[o] = nanv; if (pred) pred[o] = -1; }
+        return;
+    }
+    const int d = threadIdx.x;
+    const float* f = feats + ((long)b * T + pos) * D;
+    const float vd = d < D ? f[d] : 0.f;
+    v[d] = vd;
+    const float* ct = cc + y * D;
+    const float cd = d < D ? ct[d] : 0.f;
+    const float vn = fmaxf(sqrtf(block_sum_128(vd * vd, red)), 1e-8f);
+    const float cn = fmaxf(sqrtf(block_sum_128(cd * cd, red)), 1e-8f);
+    const float cosvt = block_sum_128((vd / vn) * (cd / cn), red);
+    // arg-max over the centred codebook (identical to codebook_splice_kernel)
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int k = threadIdx.x; k < K; k += 128) {
+        const float* c = cc + (long)k * D;
+        float dot = 0.f;
+        for (int q = 0; q < D; ++q) dot = fmaf(v[q], c[q], dot);
+        const float sim = dot * rnorm[k];
+        if (sim > best) { best = sim; besti = k; }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const float ob = __shfl_xor(best, s, 64);
+        const int oi = __shfl_xor(besti, s, 64);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bs[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; }
+    __syncthreads();
+    int lab = bi[0];
+    if (bs[1] > bs[0] || (bs[1] == bs[0] && bi[1] < bi[0])) lab = bi[1];
+    const float pd = d < D ? cc[(long)lab * D + d] : 0.f;
+    const float pn = fmaxf(sqrtf(block_sum_128(pd * pd, red)), 1e-8f);
+    const float cospt = block_sum_128((pd / pn) * (cd / cn), red);
+    if (threadIdx.x == 0) {
+        terms[o] = 1.0f - cosvt;                                     // -(cos - 1), loss_fn.py:41-43
+        cos_pt[o] = cospt;
+        if (pred) pred[o] = lab;
+    }
+}
+
+// loss = sum of the per-frame terms, in a fixed order (deterministic): double partials, tree over 256 threads
+__global__ __launch_bounds__(256) void sum_terms_kernel(const float* __restrict__ terms, long n, float* __restrict__ out) {
+    __shared__ double part[256];
+    double a = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) a += (double)terms[i];
+    part[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)part[0];
+}
+
+int si_launch_codebook_metrics(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,
+                               const float* cb_centered, const float* cb_rnorm, int K, const int64_t* target, float* terms,
+                               float* loss, int64_t* pred, float* cos_pt, hipStream_t st) {
+    if (D > 128) return si_fail(ctx, SI_EINVAL, "codebook dim %d > 128", D);
+    if (B <= 0 || Lm <= 0) return SI_OK;
+    si_prof_begin(ctx, "codebook_metrics", 2.0 * B * Lm * (double)K * D, 4.0 * B * Lm * 2.0 * D, st);
+    hipLaunchKernelGGL(codebook_metrics_kernel, dim3(Lm, B), dim3(128), 0, st, feats, T, D, frame_pos, Lm, cb_centered, cb_rnorm, K,
+                       target, terms, pred, cos_pt);
+    hipLaunchKernelGGL(sum_terms_kernel, dim3(1), dim3(256), 0, st, terms, (long)B * Lm, loss);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
 int si_launch_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,
                               const float* cb_centered, const float* cb_raw, const float* cb_rnorm, int K, float* mel, int Tm,
                               int64_t* labels, hipStream_t st) {

@@ -72,6 +72,13 @@ class InpaintingEngine:
         """`get_mel(x)` of I_ea/dataset/mel_dump.py:96-98: x (B, n) already normalised -> (B, 80, Tm) log-mel."""
         return self.ctx.mel_frontend(x, None, None, normalize=False)
 
+    def codebook_metrics(self, feats: torch.Tensor, frame_pos: torch.Tensor, lm: int, target: torch.Tensor):
+        """Loss half of the reference's cos_sim on the masked frames of `feats` (B, T, 80) against target labels
+        (B, Lm): -> dict(loss, loss_terms, pred_labels, cos_pred_target, accuracy)."""
+        loss, terms, pred, cpt = self.ctx.codebook_metrics(feats, frame_pos, lm, target)
+        return {"loss": loss[0], "loss_terms": terms, "pred_labels": pred, "cos_pred_target": cpt,
+                "accuracy": (pred == target).float().mean()}
+
     def predict_batch(self, wave16: torch.Tensor, mel: torch.Tensor, frame_pos: torch.Tensor, frame_len: int,
                       blind: bool = False, mask_start: Optional[torch.Tensor] = None,
                       mask_len: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
@@ -143,11 +150,33 @@ class Generator:
 
 
 class LossFunction:
-    """The arg-max half of `LossFunction.cos_sim` (I_ea/loss_fn.py:44-47) plus the centroid splice that follows it
-    in the script (I_ea/predict.py:184-187)."""
+    """`LossFunction` of I_ea/loss_fn.py over the engine's resident codebook: `cos_sim` (loss + arg-max labels, :29-47),
+    `cos_sim_target_labels` (:49-62), plus the centroid splice that follows the call in the script
+    (I_ea/predict.py:184-187)."""
 
     def __init__(self, engine: InpaintingEngine):
         self.engine = engine
+        self._last = None
+
+    def cos_sim(self, output: torch.Tensor, labels: torch.Tensor):
+        """output (B, Lm, 80) gathered frames, labels (B, Lm) int64 -> (loss scalar tensor, pred_labels (B, Lm)),
+        as I_ea/loss_fn.py:29-47 (called at I_ea/predict.py:171)."""
+        dev = self.engine.device
+        out = output.to(dev, torch.float32).contiguous()
+        lab = labels.to(dev, torch.int64).contiguous()
+        pos = torch.zeros(out.shape[0], dtype=torch.int32, device=dev)
+        loss, terms, pred, cpt = self.engine.ctx.codebook_metrics(out, pos, out.shape[1], lab)
+        self._last = (pred, lab, cpt)
+        return loss[0], pred
+
+    def cos_sim_target_labels(self, pred_labels: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        """cos(centred predicted centroid, centred target centroid) per frame, flattened (I_ea/loss_fn.py:49-62).
+        Served from the `cos_sim` call that produced `pred_labels` (the script always calls the two back to back,
+        I_ea/predict.py:171-173); any other label pair is an error rather than a silent host computation."""
+        if self._last is None or not (torch.equal(self._last[0], pred_labels.to(self._last[0].device)) and
+                                      torch.equal(self._last[1], labels.to(self._last[1].device))):
+            raise ValueError("cos_sim_target_labels expects the (pred_labels, labels) pair of the preceding cos_sim call")
+        return self._last[2].reshape(-1)
 
     def predict_and_splice(self, outputs: torch.Tensor, mask_pos: torch.Tensor, mask_len: int, mel: torch.Tensor):
         """outputs (B, T, 80), mask_pos (B,) int32, mel (B, 80, Tm) modified in place -> labels (B, Lm)."""

@@ -22,7 +22,7 @@ SI_MAX_CONV, SI_MAX_UPS, SI_MAX_RB, SI_MAX_DIL = 8, 8, 4, 4
 
 EXPORTS = ["si_version", "si_create", "si_destroy", "si_last_error", "si_load_weights", "si_alloc_weights",
            "si_weights_device_ptr", "si_workspace_bytes", "si_hubert_forward", "si_codebook_splice",
-           "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
+           "si_codebook_metrics", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
            "si_vocoder_samples", "si_profile_start", "si_profile_stop",
            "si_debug_capture", "si_debug_size"]
 
@@ -121,6 +121,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.si_workspace_bytes.argtypes = [vp, i32, i32, i32, C.POINTER(sz)]
     lib.si_hubert_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_codebook_splice.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp]
+    lib.si_codebook_metrics.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.si_hifigan_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_mel_frames.argtypes = [i32]
     lib.si_mel_workspace_bytes.argtypes = [vp, i32, i32, C.POINTER(sz)]
@@ -245,6 +246,20 @@ class NativeContext:
         self._check(self.lib.si_codebook_splice(self._h, _ptr(feats), B, T, _ptr(frame_pos), lm, _ptr(mel), mel.shape[2],
                                                 _ptr(labels), self._stream()), "si_codebook_splice")
         return labels
+
+    def codebook_metrics(self, feats: torch.Tensor, frame_pos: torch.Tensor, lm: int, target: torch.Tensor):
+        """-> (loss (1,), loss_terms (B, Lm), pred_labels (B, Lm) int64, cos_pred_target (B, Lm))."""
+        assert feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous() and feats.dim() == 3
+        assert frame_pos.is_cuda and frame_pos.dtype == torch.int32 and frame_pos.is_contiguous()
+        B, T, D = feats.shape
+        assert target.is_cuda and target.dtype == torch.int64 and target.is_contiguous() and tuple(target.shape) == (B, lm)
+        terms = torch.empty(B, lm, dtype=torch.float32, device=self.device)
+        cpt = torch.empty(B, lm, dtype=torch.float32, device=self.device)
+        pred = torch.empty(B, lm, dtype=torch.int64, device=self.device)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        self._check(self.lib.si_codebook_metrics(self._h, _ptr(feats), B, T, _ptr(frame_pos), lm, _ptr(target), _ptr(terms),
+                                                 _ptr(loss), _ptr(pred), _ptr(cpt), self._stream()), "si_codebook_metrics")
+        return loss, terms, pred, cpt
 
     def hifigan_forward(self, mel: torch.Tensor, stretch: bool = True) -> torch.Tensor:
         assert mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous() and mel.dim() == 3

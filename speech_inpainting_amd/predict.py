@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import os
 import sys
-from typing import Dict, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -72,6 +72,38 @@ def predict_clips(engine: InpaintingEngine, waves16: Sequence[np.ndarray], waves
     return out
 
 
+def bucket_by_length(lengths: Sequence[int], max_batch: int = 32) -> List[List[int]]:
+    """Group clip indices into batches of EXACTLY equal length (at most `max_batch` each), longest first, original
+    order kept inside a group.  HuBERT-base's GroupNorm over time and the processor's per-clip normalisation make
+    padded batches differ from the reference's one-clip-at-a-time loop (I_ea/predict.py:76-207 handles one file),
+    so ragged inputs are bucketed instead of padded (SURVEY.md section 8(d), config #5)."""
+    groups: Dict[int, List[int]] = {}
+    for i, n in enumerate(lengths):
+        groups.setdefault(int(n), []).append(i)
+    out: List[List[int]] = []
+    for n in sorted(groups, reverse=True):
+        idx = groups[n]
+        out.extend(idx[k:k + max_batch] for k in range(0, len(idx), max_batch))
+    return out
+
+
+def predict_ragged(engine: InpaintingEngine, waves16: Sequence[np.ndarray], waves22: Sequence[np.ndarray],
+                   mask_pos: Sequence[int], mask_frames: int, blind: bool = False, max_batch: int = 32) -> List[Dict[str, torch.Tensor]]:
+    """`predict_clips` over clips of DIFFERENT lengths: exact-length buckets, one engine batch per bucket; returns one
+    result dict per input clip, in input order (tensors keep their batch dimension of 1)."""
+    if not (len(waves16) == len(waves22) == len(mask_pos)):
+        raise ValueError("waves16, waves22 and mask_pos must have one entry per clip")
+    results: List[Optional[Dict[str, torch.Tensor]]] = [None] * len(waves16)
+    # a bucket must agree on BOTH sample counts (the 22.05 kHz length follows from the resampler's rounding)
+    keys = [len(a) * 1_000_003 + len(b) for a, b in zip(waves16, waves22)]
+    for idx in bucket_by_length(keys, max_batch):
+        out = predict_clips(engine, [waves16[i] for i in idx], [waves22[i] for i in idx], [mask_pos[i] for i in idx],
+                            mask_frames, blind=blind)
+        for k, i in enumerate(idx):
+            results[i] = {name: v[k:k + 1] for name, v in out.items()}
+    return results  # type: ignore[return-value]
+
+
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
     cfg = load_predict_config(argv[0] if argv else "predict.yaml")
@@ -103,6 +135,10 @@ def main(argv=None) -> int:
         exp[0, :, pos:pos + lm] = cb[labels].T.to(exp.device)
         ew = engine.vocode(exp, stretch=True)
         audio.write_wav(os.path.join(save_dir, "expected_inpaint.wav"), audio.to_int16_pcm(ew[0]), 22050)
+        m = engine.codebook_metrics(out["feats"], torch.tensor([pos], dtype=torch.int32, device=engine.device), lm,
+                                    labels[None].to(engine.device))                 # predict.py:171-173
+        print("Loss:", float(m["loss"]))
+        print("Average Cosine Similarity: ", float(m["cos_pred_target"].mean()))
         print("Target codewords: ", labels.tolist())
     print("Predicted codewords: ", out["labels"][0].tolist())
     audio.write_wav(os.path.join(save_dir, "inpainted.wav"), audio.to_int16_pcm(out["wave"][0]), 22050)

@@ -131,3 +131,13 @@ def test_arch_from_hf_config_json():
     hub = next((v for v in cfg.values() if isinstance(v, dict) and v.get("model_type") == "hubert"), hub)
     a = HubertArch.from_hf_config(hub)
     assert a == HubertArch.base()
+
+
+def test_bucket_by_length_groups_exact_lengths():
+    from speech_inpainting_amd.predict import bucket_by_length
+    lengths = [64000, 160000, 64000, 80000, 64000, 160000, 64000]
+    b = bucket_by_length(lengths, max_batch=3)
+    assert sorted(i for g in b for i in g) == list(range(len(lengths)))          # a partition
+    assert all(len({lengths[i] for i in g}) == 1 and len(g) <= 3 for g in b)      # equal length, bounded size
+    assert b == [[1, 5], [3], [0, 2, 4], [6]]                                     # longest first, input order inside
+    assert bucket_by_length([], 4) == []

@@ -102,3 +102,29 @@ def test_vocoder_is_shift_consistent():
     b = eng.vocode(shifted, stretch=False)[0]
     lo, hi = 40 * 256, 80 * 256
     assert rms(b[lo + 256:hi + 256].cpu(), a[lo:hi].cpu()) <= 1e-5
+
+
+def test_config5_ragged_lengths_are_bucketed_and_match_per_clip_oracle():
+    """configs[4]: variable-length clips (here 1.0 / 1.5 / 1.0 / 2.2 s), blind and masked, through predict_ragged:
+    every clip must equal the oracle run on that clip alone (mel front-end included)."""
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.predict import predict_ragged
+    harch, varch = HubertArch.tiny(), VocoderArch.tiny()
+    eng, (hsd, gsd, cb) = _mk(harch, varch, K=50)
+    secs = [1.0, 1.5, 1.0, 2.2]
+    w16 = [synth.synth_wave(1, int(s * 16000), 40 + i)[0].numpy() for i, s in enumerate(secs)]
+    w22 = [synth.synth_wave(1, int(s * 16000) * 22050 // 16000, 60 + i, sr=22050)[0].numpy() for i, s in enumerate(secs)]
+    pos, lm = [10, 30, 20, 55], 5
+    for blind in (False, True):
+        outs = predict_ragged(eng, w16, w22, pos, lm, blind=blind, max_batch=2)
+        assert len(outs) == 4
+        for i in range(4):
+            s22, e22 = pos[i] * 320 * 22050 // 16000, (pos[i] + lm) * 320 * 22050 // 16000
+            mel = R.masked_mel([w22[i]], None if blind else [s22], None if blind else [e22])
+            ref = R.predict_batch(hsd, harch, gsd, varch, cb, torch.from_numpy(w16[i])[None], mel, [pos[i]], lm, blind=blind)
+            got = outs[i]
+            assert got["wave"].shape == tuple(ref["wave"].shape)
+            assert torch.equal(got["labels"].cpu(), ref["labels"]), (blind, i)
+            assert rms(got["wave"].cpu(), ref["wave"]) <= 1e-4, (blind, i, rms(got["wave"].cpu(), ref["wave"]))

@@ -161,3 +161,35 @@ def test_errors_are_loud():
     bad.pop("final_layers.1.bias")
     with pytest.raises(NativeError, match="final_layers.1.bias"):
         InpaintingEngine(c["harch"], c["varch"], 100, "cuda:0").load_state(bad, c["gsd"], c["cb"])
+
+
+def test_loss_half_matches_reference_goldens():
+    """f-4: si_codebook_metrics through the C ABI vs outputs of the reference's own LossFunction (tests/golden/loss_metrics.npz)."""
+    import os
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import InpaintingEngine, LossFunction
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_metrics.npz"))
+    harch, varch = HubertArch.tiny(), VocoderArch.tiny()
+    for K in (100, 500):
+        cb = synth.synth_codebook(K, 80, synth.DEFAULT_SEED + 2)
+        eng = InpaintingEngine(harch, varch, K, "cuda:0", "fp32", "fp32").load_state(
+            synth.synth_hubert_state(harch), synth.synth_generator_state(varch), cb)
+        lf = LossFunction(eng)
+        for tag in ("near", "cnear", "far"):
+            values, labels = torch.from_numpy(g[f"{tag}_{K}_values"]), torch.from_numpy(g[f"{tag}_{K}_labels"])
+            loss, pred = lf.cos_sim(values, labels)                          # same call as I_ea/predict.py:171
+            cpt = lf.cos_sim_target_labels(pred, labels)                     # :172-173
+            ref_loss = float(g[f"{tag}_{K}_loss"])
+            assert np.array_equal(pred.cpu().numpy(), g[f"{tag}_{K}_pred"]), (K, tag)
+            assert abs(float(loss) - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (K, tag, float(loss), ref_loss)
+            assert np.allclose(cpt.cpu().numpy(), g[f"{tag}_{K}_cos_pred_target"], atol=2e-6), (K, tag)
+        # masked-frame form on (B, T, 80) features + an out-of-range target
+        feats = torch.from_numpy(g[f"cnear_{K}_values"]).cuda()
+        tgt = torch.from_numpy(g[f"cnear_{K}_labels"]).cuda()
+        pos = torch.tensor([0, 2, 4, 6], dtype=torch.int32, device="cuda")
+        m = eng.codebook_metrics(feats, pos, 3, tgt[:, :3].contiguous())
+        assert m["pred_labels"].shape == (4, 3) and torch.isfinite(m["loss"])
+        bad = tgt[:, :3].clone(); bad[1, 1] = K
+        m2 = eng.codebook_metrics(feats, pos, 3, bad.contiguous())
+        assert torch.isnan(m2["loss_terms"][1, 1]) and int(m2["pred_labels"][1, 1]) == -1

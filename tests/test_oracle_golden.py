@@ -64,3 +64,18 @@ def test_shape_known_answers():
 def test_pcm_truncates_toward_zero():
     a = torch.tensor([0.99999, -0.99999, 0.5 / 32768 * 3, -0.5 / 32768 * 3])
     assert R.to_int16_pcm(a).tolist() == [32767, -32767, 1, -1]
+
+
+def test_loss_half_matches_reference_lossfunction():
+    """f-4: cos_sim loss / labels / cos_sim_target_labels of the oracle vs the reference's LossFunction outputs."""
+    import os
+    from speech_inpainting_amd import synth
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_metrics.npz"))
+    for K in (100, 500):
+        cb = synth.synth_codebook(K, 80, synth.DEFAULT_SEED + 2)
+        for tag in ("near", "cnear", "far"):
+            values, labels = torch.from_numpy(g[f"{tag}_{K}_values"]), torch.from_numpy(g[f"{tag}_{K}_labels"])
+            loss, pred, cpt = R.cos_sim_loss(values, labels, cb)
+            assert np.array_equal(pred.numpy(), g[f"{tag}_{K}_pred"])
+            assert abs(float(loss) - float(g[f"{tag}_{K}_loss"])) <= 1e-5 * max(1.0, abs(float(g[f"{tag}_{K}_loss"])))
+            assert np.allclose(cpt.numpy(), g[f"{tag}_{K}_cos_pred_target"], atol=1e-6)

@@ -210,6 +210,34 @@ def extend_cases(out_dir):
     print("extend_mel: widths", {k: v.shape[-1] for k, v in rec.items() if k.startswith("out_")})
 
 
+def loss_cases(out_dir, tmpdir):
+    """The loss half of the reference's LossFunction (I_ea/loss_fn.py:29-62, called at predict.py:171-173): outputs near
+    the centroids (so arg-max and targets mostly agree) and far from them, K = 100 and 500, plus the class targets."""
+    rec = {}
+    for K in (100, 500):
+        cb = synth.synth_codebook(K, 80, synth.DEFAULT_SEED + 2)
+        loss = build_reference_loss(cb, tmpdir)
+        g = torch.Generator().manual_seed(100 + K)
+        B, Lm = 4, 10
+        labels = torch.randint(0, K, (B, Lm), generator=g)
+        near = cb[labels] + 0.3 * torch.randn(B, Lm, 80, generator=g)         # predictions close to their targets
+        far = -5.0 + torch.randn(B, Lm, 80, generator=g)                      # unrelated predictions
+        cnear = near - cb.mean(dim=0)                                         # what a trained head emits: centred targets
+        for tag, values in (("near", near), ("cnear", cnear), ("far", far)):
+            with torch.no_grad():
+                l, pred = loss.cos_sim(values, labels)
+                cpt = loss.cos_sim_target_labels(pred, labels)
+            rec[f"{tag}_{K}_values"] = values.numpy()
+            rec[f"{tag}_{K}_labels"] = labels.numpy().astype(np.int64)
+            rec[f"{tag}_{K}_loss"] = np.float64(float(l))
+            rec[f"{tag}_{K}_pred"] = pred.numpy().astype(np.int64)
+            rec[f"{tag}_{K}_cos_pred_target"] = cpt.numpy()
+            print(f"loss {tag} K={K}: loss {float(l):.5f}  accuracy {float((pred == labels).float().mean()):.2f}  "
+                  f"mean cos(pred, target) {float(cpt.mean()):.4f}")
+        rec[f"targets_{K}"] = loss.targets.numpy()
+    np.savez_compressed(os.path.join(out_dir, "loss_metrics.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
@@ -234,6 +262,7 @@ def main():
         "tiny_blind": lambda: run_case("tiny_blind", HubertArch.tiny(), VocoderArch.tiny(), 2, 8000, [0, 0], 0, 100, a.out, tmp,
                                        blind=True),
         "extend_mel": lambda: extend_cases(a.out),
+        "loss_metrics": lambda: loss_cases(a.out, tmp),
     }
     for k, fn in cases.items():
         if a.only and k not in a.only.split(","):

@@ -49,7 +49,8 @@ enum {
 enum {
     SI_MATH_F32 = 0,     /* v_mfma_f32_32x32x2_f32: exact fp32 fma chain */
     SI_MATH_BF16 = 1,    /* v_mfma_f32_32x32x16_bf16, operands rounded to bf16 */
-    SI_MATH_BF16X3 = 2   /* hi/lo split bf16, 3 MFMAs per product: ~2^-16 relative operand error */
+    SI_MATH_BF16X3 = 2,  /* hi/lo split bf16, 3 MFMAs per product: ~2^-16 relative operand error */
+    SI_MATH_F16 = 3      /* v_mfma_f32_32x32x16_f16, operands rounded to fp16 (saturating): 2^-12 relative operand error */
 };
 
 #define SI_MAX_CONV 8

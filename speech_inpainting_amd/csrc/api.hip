@@ -244,7 +244,7 @@ int check_desc(si_ctx* ctx, const si_model_desc* d) {
     for (int j = 0; j < d->num_rb; ++j)
         if (d->rb_kernels[j] % 2 == 0) return si_fail(ctx, SI_EINVAL, "resblock kernel %d must be odd", d->rb_kernels[j]);
     for (int m : {d->encoder_math, d->vocoder_math})
-        if (m < SI_MATH_F32 || m > SI_MATH_BF16X3) return si_fail(ctx, SI_EINVAL, "unknown math mode %d", m);
+        if (m < SI_MATH_F32 || m > SI_MATH_F16) return si_fail(ctx, SI_EINVAL, "unknown math mode %d", m);
     return SI_OK;
 }
 
@@ -254,6 +254,15 @@ unsigned short h_f2bf(float f) {
     if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
+}
+// fp32 -> fp16, round to nearest even, saturating at +-65504 (NaN stays NaN)
+unsigned short h_f2h(float f) {
+    if (f != f) return 0x7e00;
+    const float c = f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f);
+    const _Float16 h = (_Float16)c;
+    unsigned short u;
+    memcpy(&u, &h, 2);
+    return u;
 }
 float h_bf2f(unsigned short h) { unsigned u = ((unsigned)h) << 16; float f; memcpy(&f, &u, 4); return f; }
 
@@ -316,6 +325,7 @@ struct Packer {
     void put(const GemmW& G, int g, int tap, int n, int ci, float v) {
         const size_t idx = (((size_t)g * G.ntaps + tap) * G.Npad + n) * G.Cin + ci;
         if (G.math == SI_MATH_F32) { fptr(G.w)[idx] = v; return; }
+        if (G.math == SI_MATH_F16) { reinterpret_cast<unsigned short*>(out.data() + G.w)[idx] = h_f2h(v); return; }
         const unsigned short hi = h_f2bf(v);
         reinterpret_cast<unsigned short*>(out.data() + G.w)[idx] = hi;
         if (G.math == SI_MATH_BF16X3) reinterpret_cast<unsigned short*>(out.data() + G.w_lo)[idx] = h_f2bf(v - h_bf2f(hi));

@@ -41,12 +41,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 template <int MATH> struct LdsElem { typedef float type; static constexpr int PAD = 4; };
 template <> struct LdsElem<SI_MATH_BF16> { typedef unsigned short type; static constexpr int PAD = 8; };
 template <> struct LdsElem<SI_MATH_BF16X3> { typedef unsigned short type; static constexpr int PAD = 8; };
+template <> struct LdsElem<SI_MATH_F16> { typedef unsigned short type; static constexpr int PAD = 8; };
 
 // float4 of the activation tile a thread holds in flight: 10 covers 128-row tiles (<= 320 rows at BK = 32),
 // 12 the 256-row tiles (306 rows) and the positional conv (383 rows at BK = 16)
@@ -163,6 +166,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void tapgemm_kernel(cons
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
                 if constexpr (MATH == SI_MATH_F32) {
                     *reinterpret_cast<f32x4*>(dst + r * LD + 4 * j) = v;
+                } else if constexpr (MATH == SI_MATH_F16) {
+                    // fp16 operands (11-bit significand): saturate instead of overflowing to infinity
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fminf(__builtin_fmaxf(v[e], -65504.f), 65504.f);
+                    *reinterpret_cast<f16x4*>(dst + r * LD + 4 * j) = __builtin_convertvector(v, f16x4);
                 } else {
                     // vector casts lower to v_cvt_pk_bf16_f32 (round-to-nearest-even, 2 elements per instruction)
                     const bf16x4 hi = __builtin_convertvector(v, bf16x4);
@@ -257,6 +265,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void tapgemm_kernel(cons
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                         }
+                } else if constexpr (MATH == SI_MATH_F16) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[i]), __builtin_bit_cast(f16x8, bh[j]), acc[i][j], 0, 0, 0);
                 } else {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
@@ -483,12 +497,12 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     }
     const int mtiles = (p.M + BM - 1) / BM;
     dim3 grid((unsigned)(p.nseg * mtiles * ((p.N + BN - 1) / BN)), (unsigned)p.groups);
-    static const char* const math_names[] = {"f32", "bf16", "bf16x3"};
+    static const char* const math_names[] = {"f32", "bf16", "bf16x3", "f16"};
     char name[48];
     snprintf(name, sizeof(name), "tapgemm_%s_%dx%d%s", math_names[MATH], BM, BN, NT == 512 ? "w8" : "");
     const double macs = p.algo_macs > 0 ? p.algo_macs : (double)p.nseg * p.M * p.N * p.groups * (double)p.Cin * p.ntaps;
     double bytes = 4.0 * p.nseg * ((double)p.Lin * p.Cin * p.groups + (double)p.M * p.N * p.groups * (1 + (p.res ? 1 : 0) + (p.accumulate ? 1 : 0))) +
-                   (double)p.groups * p.ntaps * p.N * p.Cin * (MATH == SI_MATH_F32 ? 4 : (MATH == SI_MATH_BF16 ? 2 : 4));
+                   (double)p.groups * p.ntaps * p.N * p.Cin * (MATH == SI_MATH_F32 || MATH == SI_MATH_BF16X3 ? 4 : 2);
     si_prof_begin(ctx, name, 2.0 * macs, bytes, st);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, p);
     si_prof_end(ctx, st);
@@ -556,6 +570,7 @@ int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t
         case SI_MATH_F32: return k32 ? launch_math<SI_MATH_F32, 32>(ctx, p, st) : launch_math<SI_MATH_F32, 16>(ctx, p, st);
         case SI_MATH_BF16: return k32 ? launch_math<SI_MATH_BF16, 32>(ctx, p, st) : launch_math<SI_MATH_BF16, 16>(ctx, p, st);
         case SI_MATH_BF16X3: return k32 ? launch_math<SI_MATH_BF16X3, 32>(ctx, p, st) : launch_math<SI_MATH_BF16X3, 16>(ctx, p, st);
+        case SI_MATH_F16: return k32 ? launch_math<SI_MATH_F16, 32>(ctx, p, st) : launch_math<SI_MATH_F16, 16>(ctx, p, st);
     }
     return si_fail(ctx, SI_EINVAL, "tapgemm: unknown math mode %d", math);
 }

@@ -17,7 +17,7 @@ from .arch import HubertArch, VocoderArch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SI_HIP_LIB") or os.path.join(_HERE, "libsi_hip.so")   # SI_HIP_LIB: A/B builds of the library
 
-SI_MATH = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2}
+SI_MATH = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, "fp16": 3, "f16": 3}
 SI_MAX_CONV, SI_MAX_UPS, SI_MAX_RB, SI_MAX_DIL = 8, 8, 4, 4
 
 EXPORTS = ["si_version", "si_create", "si_destroy", "si_last_error", "si_load_weights", "si_alloc_weights",

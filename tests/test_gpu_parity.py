@@ -95,7 +95,7 @@ def test_bf16_encoder_mode_reports_label_agreement():
 
 
 @pytest.mark.parametrize("name,voc,tol", [("tiny_group", "bf16x3", 1e-5), ("base_4s", "bf16x3", 1e-5), ("large_4s", "bf16x3", 1e-5),
-                                          ("base_4s", "bf16", 1e-3)])
+                                          ("base_4s", "bf16", 1e-3), ("base_4s", "fp16", 2e-4), ("tiny_group", "fp16", 2e-4)])
 def test_vocoder_split_bf16_modes(name, voc, tol):
     """bf16x3 (hi/lo split, 3 MFMAs per product) is the benchmark's vocoder arithmetic: it must stay fp32-equivalent
     (measured 1.5e-6 RMS at full size).  Plain bf16 is only required to meet the north-star gate (measured 7.4e-4)."""

@@ -521,8 +521,9 @@ size_t vocoder_ws_bytes(const si_ctx* ctx, int B, int Tm, int stretch) {
     long L = Tout; int c = d.up_initial_channel;
     for (int i = 0; i < d.num_ups; ++i) { L *= d.up_rates[i]; c /= 2; lc_max = std::max(lc_max, (size_t)L * c); }
     const size_t sub = (size_t)(Bc + 1) / 2;                 // two half-chunks, one per stream
-    size_t f = 2 * (sub * Tout * ctx->lay.mel_ld + 6 * sub * lc_max);
-    f = std::max(f, (size_t)Bc * Tout * ctx->lay.mel_ld + 6 * (size_t)Bc * lc_max);
+    // 6 fp32 activation buffers + 6 half-size buffers for the operand-ready 16-bit copies (bf16 / fp16 modes)
+    size_t f = 2 * (sub * Tout * ctx->lay.mel_ld + 9 * sub * lc_max);
+    f = std::max(f, (size_t)Bc * Tout * ctx->lay.mel_ld + 9 * (size_t)Bc * lc_max);
     return f * 4 + 32 * 256;
 }
 
@@ -533,6 +534,7 @@ TapGemmParams gemm_params(const si_ctx* ctx, const GemmW& G) {
     p.bias = G.has_bias ? reinterpret_cast<const float*>(ctx->wdev + G.bias) : nullptr;
     p.Cin = G.Cin; p.N = G.N; p.Npad = G.Npad; p.ntaps = G.ntaps; p.groups = G.groups;
     p.stride = 1; p.dil = 1; p.pad = 0; p.pro_slope = 1.f; p.act = SI_ACT_NONE; p.alpha = 1.f; p.accumulate = 0;
+    p.out16_slope = 1.f;
     p.nseg = 1;
     return p;
 }
@@ -801,10 +803,18 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
     Carver W{static_cast<char*>(workspace), workspace_bytes};
     float* ext_s[2];
     float* buf_s[2][6];
+    unsigned short* h16_s[2][6];
     for (int h = 0; h < nstr; ++h) {
         ext_s[h] = W.floats((size_t)sub_max * Tout * Ly.mel_ld);
         for (auto& b : buf_s[h]) b = W.floats((size_t)sub_max * lc_max);
+        for (auto& b : h16_s[h]) b = reinterpret_cast<unsigned short*>(W.bytes((size_t)sub_max * lc_max * 2));
     }
+    // Operand-ready activations (bf16 / fp16 vocoder): every producer also writes type16(leaky_relu(x, 0.1)) -- exactly
+    // what the next convolution would compute while staging -- so consumers copy 2-byte operands instead of loading
+    // fp32 and converting; the ResBlock intermediate exists only in that form.  Same arithmetic, bit-identical output;
+    // 20-40 % less HBM / L2 traffic on the convolution inputs.  SI_VOC_OPREADY=0 restores the fp32-input path.
+    static const int opready_env = getenv("SI_VOC_OPREADY") ? atoi(getenv("SI_VOC_OPREADY")) : 1;
+    const bool opr = opready_env && (d.vocoder_math == SI_MATH_BF16 || d.vocoder_math == SI_MATH_F16);
     if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: vocoder workspace carve exceeded its own estimate");
     if (nstr == 2 && !ctx->aux_stream) {
         SI_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
@@ -816,16 +826,18 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
     static const char* stn[] = {"stage0", "stage1", "stage2", "stage3", "stage4", "stage5", "stage6", "stage7"};
 
     // the generator on clips [b0, b0 + Bc) with its own scratch, enqueued on stream `st`
-    auto run = [&](int b0, int Bc, float* ext, float* const* buf, hipStream_t st) -> int {
+    auto run = [&](int b0, int Bc, float* ext, float* const* buf, unsigned short* const* h16, hipStream_t st) -> int {
         int rc;
         // A14: stretch + transpose to channels-last
         if ((rc = si_launch_extend_mel(ctx, mel + (size_t)b0 * d.num_mels * Tm, Bc, d.num_mels, Tm, (int)Tout, stretch, ext, Ly.mel_ld, st))) return rc;
         // B1: conv_pre
         float* x = buf[0];
         float* xs = buf[1];
+        unsigned short *x16 = h16[0], *xs16 = h16[1], *U16 = h16[2], *t16 = h16[3];
         {
             TapGemmParams p = gemm_params(ctx, Ly.pre);
             p.x = ext; p.out = x;
+            if (opr) { p.out16 = x16; p.out16_slope = 0.1f; }
             p.nseg = Bc; p.Lin = (int)Tout; p.M = (int)Tout; p.ldx = Ly.mel_ld; p.x_seg_stride = Tout * Ly.mel_ld;
             p.algo_macs = (double)Bc * Tout * d.up_initial_channel * (double)d.num_mels * 7;
             p.pad = 3; p.ldo = d.up_initial_channel; p.o_seg_stride = Tout * d.up_initial_channel; p.olimit = p.o_seg_stride;
@@ -840,6 +852,7 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
             {
                 TapGemmParams p = gemm_params(ctx, Ly.ups[i]);
                 p.x = x; p.out = U;
+                if (opr) { p.x = nullptr; p.x16 = x16; p.out16 = U16; p.out16_slope = 0.1f; }
                 p.nseg = Bc; p.Lin = (int)Lc; p.M = (int)((pad + Lo - 1) / u + 1); p.ldx = c; p.x_seg_stride = Lc * c;
                 p.dil = -1; p.ldo = u * cout; p.o_seg_stride = Lo * cout; p.ooff = -(long)pad * cout; p.olimit = Lo * cout;
                 p.pro_slope = 0.1f;
@@ -852,29 +865,41 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                 const ResW& R = Ly.rbs[(size_t)i * nk + j];
                 const int rk = d.rb_kernels[j];
                 const float* y = U;
+                const unsigned short* y16 = U16;
                 for (int n = 0; n < d.num_dil; ++n) {
                     const int dl = d.rb_dilations[j][n];
                     float* t = buf[3];
                     TapGemmParams p = gemm_params(ctx, R.c1[n]);
                     p.x = y; p.out = t;
+                    if (opr) { p.x = nullptr; p.x16 = y16; p.out = nullptr; p.out16 = t16; p.out16_slope = 0.1f; }
                     p.nseg = Bc; p.Lin = (int)Lo; p.M = (int)Lo; p.ldx = cout; p.x_seg_stride = Lo * cout;
                     p.dil = dl; p.pad = dl * (rk - 1) / 2; p.ldo = cout; p.o_seg_stride = Lo * cout; p.olimit = p.o_seg_stride;
                     p.pro_slope = 0.1f;
                     if ((rc = si_launch_tapgemm(ctx, R.c1[n].math, p, st))) return rc;
                     const bool last = (n == d.num_dil - 1);
                     float* ynext = last ? xs : buf[4 + (n & 1)];
+                    unsigned short* ynext16 = last ? xs16 : h16[4 + (n & 1)];
                     TapGemmParams q = gemm_params(ctx, R.c2[n]);
                     q.x = t; q.out = ynext; q.res = y;
+                    if (opr) {
+                        q.x = nullptr; q.x16 = t16;
+                        // the 16-bit copy is wanted by the next c1 of this block, or -- once the MRF mean is complete --
+                        // by the next stage's upsampler; conv_post reads fp32
+                        const bool want16 = !last || (j == nk - 1 && i + 1 < d.num_ups);
+                        if (want16) { q.out16 = ynext16; q.out16_slope = 0.1f; }
+                    }
                     q.nseg = Bc; q.Lin = (int)Lo; q.M = (int)Lo; q.ldx = cout; q.x_seg_stride = Lo * cout;
                     q.dil = 1; q.pad = (rk - 1) / 2; q.ldo = cout; q.o_seg_stride = Lo * cout; q.olimit = q.o_seg_stride;
                     q.pro_slope = 0.1f;
                     if (last) { q.alpha = 1.0f / nk; q.accumulate = (j > 0); }
                     if ((rc = si_launch_tapgemm(ctx, R.c2[n].math, q, st))) return rc;
                     y = ynext;
+                    y16 = ynext16;
                 }
             }
             if ((rc = si_tap(ctx, stn[i], xs, (long)Bc * Lo * cout, st))) return rc;
             std::swap(x, xs);
+            std::swap(x16, xs16);
             Lc = Lo; c = cout;
         }
         // B4: leaky_relu(0.01) -> conv_post -> tanh
@@ -889,9 +914,9 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
             SI_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));        // the second half starts after everything already queued
             SI_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
         }
-        if ((rc = run(b0, first, ext_s[0], buf_s[0], st))) return rc;
+        if ((rc = run(b0, first, ext_s[0], buf_s[0], h16_s[0], st))) return rc;
         if (first < Bc) {
-            if ((rc = run(b0 + first, Bc - first, ext_s[1], buf_s[1], ctx->aux_stream))) return rc;
+            if ((rc = run(b0 + first, Bc - first, ext_s[1], buf_s[1], h16_s[1], ctx->aux_stream))) return rc;
             SI_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
             SI_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
         }

@@ -28,12 +28,15 @@ typedef unsigned short bf16_t;   // raw bf16 bits
 enum { SI_ACT_NONE = 0, SI_ACT_GELU = 1 };
 
 struct TapGemmParams {
-    const float* x;        // [nseg][Lin][ldx] fp32, channels-last
+    const float* x;        // [nseg][Lin][ldx] fp32, channels-last (NULL when x16 is given)
+    const unsigned short* x16;  // same geometry, operand-ready: already activated and rounded to the math mode's 16-bit type
     const void* w;         // [groups][ntaps][Npad][Cin]  (fp32, or bf16 hi plane)
     const void* w_lo;      // bf16x3: lo plane, same layout
     const float* bias;     // [groups*N] or nullptr
     const float* res;      // residual, indexed like out, or nullptr
-    float* out;
+    float* out;            // fp32 output (may be NULL when only out16 is wanted)
+    unsigned short* out16; // optional operand-ready copy for the consumer: type16(leaky_relu(v, out16_slope)), indexed like out
+    float out16_slope;     // the consumer's prologue slope (1 = identity)
     int nseg, Lin, M;      // segments (clips), input rows and output rows per segment
     int ldx;               // input row stride (floats)
     long x_seg_stride;     // floats between segments

@@ -39,6 +39,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -74,8 +75,11 @@ __device__ unsigned long long si_tg_stamps[24];
 // LINEAR (ntaps == 1) is a compile-time variant so that each instantiation carries only its own loop and register sets.
 // __launch_bounds__(256, 2): two waves per SIMD = two workgroups per CU (what the LDS footprint allows); without the
 // second argument the allocator takes up to 235 VGPRs + 64 accumulators and halves the occupancy.
-template <int MATH, int BM, int BN, int WARPS_M, int WARPS_N, int BK, bool LINEAR>
+// A16: the activations arrive operand-ready (p.x16: 16-bit, already in the MFMA operand type of MATH, prologue
+// activation already applied by the producer's epilogue): staging is an 8-byte copy per 4 channels, no conversion.
+template <int MATH, int BM, int BN, int WARPS_M, int WARPS_N, int BK, bool LINEAR, bool A16 = false>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void tapgemm_kernel(const TapGemmParams p) {
+    static_assert(!A16 || MATH == SI_MATH_BF16 || MATH == SI_MATH_F16, "operand-ready activations are 16-bit single-plane");
     static_assert(WARPS_M * WARPS_N == 4 || WARPS_M * WARPS_N == 8, "4 or 8 waves per workgroup");
     constexpr int NT = 64 * WARPS_M * WARPS_N;          // threads per workgroup
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
@@ -121,7 +125,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void tapgemm_kernel(cons
     elem_t* As = reinterpret_cast<elem_t*>(smem);                 // [abufs][PLANES][rowsA][LD]
     elem_t* Bs = As + (size_t)abufs * a_tile;                     // [2][PLANES][BN][LD]
 
-    const float* xs = p.x + (long)seg * p.x_seg_stride + (long)g * p.Cin;
+    const float* xs = A16 ? nullptr : p.x + (long)seg * p.x_seg_stride + (long)g * p.Cin;
+    const unsigned short* xs16 = A16 ? p.x16 + (long)seg * p.x_seg_stride + (long)g * p.Cin : nullptr;
     const size_t wplane = (size_t)ntaps * p.Npad * p.Cin;        // elements per group
     const float slope = p.pro_slope;
 
@@ -150,7 +155,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void tapgemm_kernel(cons
             if (idx < nA) {
                 const int r = idx / V4, j = idx - r * V4;
                 const int grow = base_in + r;
-                if (grow >= 0 && grow < p.Lin) ra[LO + i] = *reinterpret_cast<const f32x4*>(xs + (long)grow * p.ldx + c0 + 4 * j);
+                if constexpr (A16) {
+                    if (grow >= 0 && grow < p.Lin) {
+                        const f32x2 t = *reinterpret_cast<const f32x2*>(xs16 + (long)grow * p.ldx + c0 + 4 * j);
+                        ra[LO + i][0] = t[0]; ra[LO + i][1] = t[1];
+                    }
+                } else {
+                    if (grow >= 0 && grow < p.Lin) ra[LO + i] = *reinterpret_cast<const f32x4*>(xs + (long)grow * p.ldx + c0 + 4 * j);
+                }
             }
         }
     };
@@ -162,6 +174,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void tapgemm_kernel(cons
             if (idx < nA) {
                 const int r = idx / V4, j = idx - r * V4;
                 f32x4 v = ra[LO + i];
+                if constexpr (A16) {
+                    *reinterpret_cast<f32x2*>(dst + r * LD + 4 * j) = f32x2{v[0], v[1]};
+                    continue;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
                 if constexpr (MATH == SI_MATH_F32) {
@@ -405,14 +421,20 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void tapgemm_kernel(cons
     // this segment's output: the hardware range check drops rows >= M, the negative offsets of the ConvTranspose
     // phase layout and (voffset forced to 2^31) the columns >= N, so no per-element predicate or address register
     // survives -- a lane keeps one byte offset per 32x32 tile and adds a scalar row step.
-    float* const outp = p.out + (long)seg * p.o_seg_stride;
+    // p.out may be NULL when only the operand-ready 16-bit copy is wanted (p.out16); the descriptor then has 0 records
+    float* const outp = p.out ? p.out + (long)seg * p.o_seg_stride : nullptr;
     const float* const resp = p.res ? p.res + (long)seg * p.o_seg_stride : outp;
     const bool has_res = p.res != nullptr;
     const bool acc_out = p.accumulate != 0;
+    const bool has_out = p.out != nullptr;
+    const bool has_o16 = p.out16 != nullptr;
+    const float slope16 = p.out16_slope;
     const bool gelu = p.act == SI_ACT_GELU;
     const int nbytes = (int)p.olimit * 4;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, nbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(resp), 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, has_out ? nbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(resp), 0, resp ? nbytes : 0, 0x00020000);
+    unsigned short* const o16p = has_o16 ? p.out16 + (long)seg * p.o_seg_stride : nullptr;
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(o16p, 0, has_o16 ? nbytes / 2 : 0, 0x00020000);
     const int rstep = p.ldo * 4;                                   // bytes between output rows
     int vb[TM][TN];
     float bv[TN];
@@ -457,7 +479,22 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void tapgemm_kernel(cons
                 if (has_res) v += rv[i][j][r];
                 v *= p.alpha;
                 if (acc_out) v += ov[i][j][r];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, vb[i][j] + ((r & 3) + 8 * (r >> 2)) * rstep, 0, 0);
+                const int off = vb[i][j] + ((r & 3) + 8 * (r >> 2)) * rstep;
+                if (has_out) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, off, 0, 0);
+                if constexpr (MATH == SI_MATH_BF16 || MATH == SI_MATH_F16) {
+                    if (has_o16) {      // operand-ready copy for the consumer: its prologue activation, then its operand rounding
+                        float w = v > 0.f ? v : v * slope16;
+                        unsigned short h;
+                        if constexpr (MATH == SI_MATH_F16) {
+                            w = __builtin_fminf(__builtin_fmaxf(w, -65504.f), 65504.f);
+                            h = __builtin_bit_cast(unsigned short, (_Float16)w);
+                        } else {
+                            h = __builtin_bit_cast(unsigned short, (__bf16)w);
+                        }
+                        // a masked column carries offset 2^31: halving it would bring it back into range
+                        __builtin_amdgcn_raw_buffer_store_b16(h, hrsrc, vb[i][j] == (int)0x80000000 ? (int)0x80000000 : off / 2, 0, 0);
+                    }
+                }
             }
 #ifdef TG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // include the store drain: a wave cannot retire before it
@@ -489,11 +526,18 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     const size_t lds = (size_t)PLANES * ((size_t)abufs * rowsA + 2 * BN) * LD * sizeof(elem_t);
     if (lds > 160 * 1024) return si_fail(ctx, SI_EINVAL, "tapgemm: LDS tile of %zu bytes exceeds 160 KiB", lds);
     const bool lin = p.ntaps == 1;
-    auto kern = lin ? tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK, true> : tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK, false>;
-    static size_t lds_set[2] = {0, 0};                             // per instantiation
-    if (lds > 64 * 1024 && lds > lds_set[lin]) {
+    const bool a16 = p.x16 != nullptr;
+    void (*kern)(const TapGemmParams) = lin ? tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK, true> : tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK, false>;
+    if constexpr (MATH == SI_MATH_BF16 || MATH == SI_MATH_F16) {
+        if (a16) kern = lin ? tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK, true, true> : tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK, false, true>;
+    } else if (a16) {
+        return si_fail(ctx, SI_EINVAL, "tapgemm: operand-ready (16-bit) activations need the bf16 or fp16 math mode");
+    }
+    static size_t lds_set[4] = {0, 0, 0, 0};                       // per instantiation
+    const int ki = (lin ? 1 : 0) + (a16 ? 2 : 0);
+    if (lds > 64 * 1024 && lds > lds_set[ki]) {
         SI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set[lin] = lds;
+        lds_set[ki] = lds;
     }
     const int mtiles = (p.M + BM - 1) / BM;
     dim3 grid((unsigned)(p.nseg * mtiles * ((p.N + BN - 1) / BN)), (unsigned)p.groups);
@@ -501,7 +545,9 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     char name[48];
     snprintf(name, sizeof(name), "tapgemm_%s_%dx%d%s", math_names[MATH], BM, BN, NT == 512 ? "w8" : "");
     const double macs = p.algo_macs > 0 ? p.algo_macs : (double)p.nseg * p.M * p.N * p.groups * (double)p.Cin * p.ntaps;
-    double bytes = 4.0 * p.nseg * ((double)p.Lin * p.Cin * p.groups + (double)p.M * p.N * p.groups * (1 + (p.res ? 1 : 0) + (p.accumulate ? 1 : 0))) +
+    // algorithmic HBM bytes: input once, every output copy once, residual / accumulate reads, weights once
+    const double outs = (double)p.M * p.N * p.groups;
+    double bytes = p.nseg * ((a16 ? 2.0 : 4.0) * p.Lin * p.Cin * p.groups + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0) + (p.accumulate ? 4 : 0))) +
                    (double)p.groups * p.ntaps * p.N * p.Cin * (MATH == SI_MATH_F32 || MATH == SI_MATH_BF16X3 ? 4 : 2);
     si_prof_begin(ctx, name, 2.0 * macs, bytes, st);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, p);
@@ -550,6 +596,11 @@ int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t
     if (p.Npad % si_pick_bn(p.N) != 0 || p.Npad < p.N)
         return si_fail(ctx, SI_EINVAL, "tapgemm: Npad=%d does not match N=%d", p.Npad, p.N);
     if (p.M <= 0 || p.nseg <= 0) return SI_OK;
+    if (!p.x == !p.x16) return si_fail(ctx, SI_EINVAL, "tapgemm: exactly one of x (fp32) and x16 (operand-ready) must be given");
+    if (!p.out && !p.out16) return si_fail(ctx, SI_EINVAL, "tapgemm: no output");
+    if (p.accumulate && !p.out) return si_fail(ctx, SI_EINVAL, "tapgemm: accumulate needs the fp32 output");
+    if (p.out16 && math != SI_MATH_BF16 && math != SI_MATH_F16)
+        return si_fail(ctx, SI_EINVAL, "tapgemm: the 16-bit output copy exists in the bf16 and fp16 math modes only");
     // The epilogue masks through a buffer descriptor of olimit*4 bytes: byte offsets of every tile row (valid or not)
     // must stay below 2^31, and rows >= M must fall outside the descriptor.
     const long ooff_abs = p.ooff < 0 ? -p.ooff : p.ooff;

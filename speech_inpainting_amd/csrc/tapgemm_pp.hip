@@ -419,7 +419,7 @@ static int pp_launch(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
 
 // SI_OK when launched, negative on error, 1 when the shape is not covered (the caller falls back to tapgemm.hip).
 int si_launch_tapgemm_pp(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t st) {
-    if (p.ntaps < 2 || p.Cin % 32 != 0 || p.N < 128 || p.M <= 256 || p.groups != 1) return 1;
+    if (p.ntaps < 2 || p.Cin % 32 != 0 || p.N < 128 || p.M <= 256 || p.groups != 1 || p.x16 || p.out16 || !p.out) return 1;
     if ((long)p.Lin * p.ldx * 4 >= (1L << 31)) return 1;           // 32-bit byte offsets into the segment's input
     switch (math) {
         case SI_MATH_F32: return pp_launch<SI_MATH_F32>(ctx, p, st);

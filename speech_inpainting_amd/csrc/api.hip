@@ -503,7 +503,9 @@ size_t encoder_ws_bytes(const si_model_desc& d, int B, int N) {
     const size_t BT = (size_t)B * std::max(e.T, 1);
     size_t f = 2 * (size_t)B * cmax + BT * d.conv_dim[d.num_conv - 1] + BT * d.hidden_size * 3 + BT * 3 * d.hidden_size + BT * d.intermediate_size +
                (size_t)B * d.conv_dim[0] * 2;
-    return f * 4 + (size_t)B * 16 + si_conv0_partials_bytes(B, N) + 32 * 256;
+    // bf16 operand-ready copies (encoder in bf16 mode): LN(features), hidden, attention output, FFN intermediate
+    const size_t h16 = (BT * d.conv_dim[d.num_conv - 1] + 2 * BT * d.hidden_size + BT * d.intermediate_size) * 2;
+    return f * 4 + h16 + (size_t)B * 16 + si_conv0_partials_bytes(B, N) + 40 * 256;
 }
 
 // Clips per vocoder pass.  Measured on MI355X (B = 32, fp32): 4 -> 109 ms/step, 8 -> 93, 16 -> 89, 32 -> 88: small
@@ -540,9 +542,11 @@ TapGemmParams gemm_params(const si_ctx* ctx, const GemmW& G) {
 }
 
 // y(rows x N) = x(rows x K) W^T + b [+act] [+res]
-int linear(si_ctx* ctx, const GemmW& G, const float* x, float* y, long rows, int act, const float* res, hipStream_t st) {
+// x16 / y16: operand-ready bf16 input (instead of x) / additional-or-only bf16 output, see TapGemmParams
+int linear(si_ctx* ctx, const GemmW& G, const float* x, float* y, long rows, int act, const float* res, hipStream_t st,
+           const unsigned short* x16 = nullptr, unsigned short* y16 = nullptr) {
     TapGemmParams p = gemm_params(ctx, G);
-    p.x = x; p.out = y; p.res = res; p.act = act;
+    p.x = x16 ? nullptr : x; p.x16 = x16; p.out = y; p.out16 = y16; p.res = res; p.act = act;
     p.nseg = 1; p.Lin = (int)rows; p.M = (int)rows; p.ldx = G.Cin; p.x_seg_stride = 0;
     p.ldo = G.N; p.o_seg_stride = 0; p.ooff = 0; p.olimit = rows * G.N;
     return si_launch_tapgemm(ctx, G.math, p, st);
@@ -661,6 +665,16 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     float* att = W.floats(BT * H);
     float* qkv = W.floats(BT * 3 * H);
     float* ffn = W.floats(BT * I);
+    // Operand-ready bf16 activations for the encoder GEMMs (bf16 mode): LayerNorm, attention and the FFN's first GEMM
+    // also / only write bf16(x) -- the rounding the consuming GEMM would apply while staging -- so the four GEMMs of a
+    // layer load 2-byte operands (their dominant traffic: M = B*T rows re-read by every N-tile) and skip the
+    // conversion.  Bit-identical to converting in the consumer.  SI_ENC_OPREADY=0 restores fp32 inputs.
+    static const int enc_opr_env = getenv("SI_ENC_OPREADY") ? atoi(getenv("SI_ENC_OPREADY")) : 1;
+    const bool e16 = enc_opr_env && d.encoder_math == SI_MATH_BF16;
+    unsigned short* lnf16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * CF * 2)) : nullptr;
+    unsigned short* h16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * H * 2)) : nullptr;
+    unsigned short* att16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * H * 2)) : nullptr;
+    unsigned short* ffn16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * I * 2)) : nullptr;
     if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: encoder workspace carve exceeded its own estimate");
 
     int rc;
@@ -695,10 +709,10 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     // A3: LN + projection
     const float* pin = feat;
     if (d.feat_proj_layer_norm) {
-        if ((rc = si_launch_layernorm(ctx, feat, nullptr, wf(ctx, L.fp_ln_g), wf(ctx, L.fp_ln_b), lnf, BT, CF, d.layer_norm_eps, 0, st))) return rc;
+        if ((rc = si_launch_layernorm(ctx, feat, nullptr, wf(ctx, L.fp_ln_g), wf(ctx, L.fp_ln_b), lnf, BT, CF, d.layer_norm_eps, 0, st, lnf16))) return rc;
         pin = lnf;
     }
-    if ((rc = linear(ctx, L.proj, pin, h, BT, SI_ACT_NONE, nullptr, st))) return rc;
+    if ((rc = linear(ctx, L.proj, pin, h, BT, SI_ACT_NONE, nullptr, st, d.feat_proj_layer_norm ? lnf16 : nullptr))) return rc;
     if ((rc = si_tap(ctx, "projected", h, BT * H, st))) return rc;
     // A4: h2 = h + gelu(pos_conv(h) + b)
     {
@@ -711,7 +725,7 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     }
     const float eps = d.layer_norm_eps;
     if (!d.stable_layer_norm) {
-        if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, L.enc_ln_g), wf(ctx, L.enc_ln_b), h, BT, H, eps, 0, st))) return rc;
+        if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, L.enc_ln_g), wf(ctx, L.enc_ln_b), h, BT, H, eps, 0, st, h16))) return rc;
     } else {
         std::swap(h, h2);
     }
@@ -719,22 +733,22 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     // A5..A8
     for (int l = 0; l < d.num_layers; ++l) {
         const LayerW& Wl = L.layers[l];
-        if (!d.stable_layer_norm) {       // post-LN (modeling_hubert.py:371-404)
-            if ((rc = linear(ctx, Wl.qkv, h, qkv, BT, SI_ACT_NONE, nullptr, st))) return rc;
-            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st))) return rc;
-            if ((rc = linear(ctx, Wl.out, att, h2, BT, SI_ACT_NONE, h, st))) return rc;
-            if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h, BT, H, eps, 0, st))) return rc;
-            if ((rc = linear(ctx, Wl.ffn1, h, ffn, BT, SI_ACT_GELU, nullptr, st))) return rc;
-            if ((rc = linear(ctx, Wl.ffn2, ffn, h2, BT, SI_ACT_NONE, h, st))) return rc;
-            if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h, BT, H, eps, 0, st))) return rc;
+        if (!d.stable_layer_norm) {       // post-LN (modeling_hubert.py:371-404); h16 = bf16(h) when e16
+            if ((rc = linear(ctx, Wl.qkv, h, qkv, BT, SI_ACT_NONE, nullptr, st, h16))) return rc;
+            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16))) return rc;
+            if ((rc = linear(ctx, Wl.out, att, h2, BT, SI_ACT_NONE, h, st, att16))) return rc;
+            if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h, BT, H, eps, 0, st, h16))) return rc;
+            if ((rc = linear(ctx, Wl.ffn1, h, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16))) return rc;
+            if ((rc = linear(ctx, Wl.ffn2, ffn, h2, BT, SI_ACT_NONE, h, st, ffn16))) return rc;
+            if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h, BT, H, eps, 0, st, h16))) return rc;
         } else {                          // pre-LN "stable" (modeling_hubert.py:504-547); residual adds are in place
-            if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h2, BT, H, eps, 0, st))) return rc;
-            if ((rc = linear(ctx, Wl.qkv, h2, qkv, BT, SI_ACT_NONE, nullptr, st))) return rc;
-            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st))) return rc;
-            if ((rc = linear(ctx, Wl.out, att, h, BT, SI_ACT_NONE, h, st))) return rc;
-            if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h2, BT, H, eps, 0, st))) return rc;
-            if ((rc = linear(ctx, Wl.ffn1, h2, ffn, BT, SI_ACT_GELU, nullptr, st))) return rc;
-            if ((rc = linear(ctx, Wl.ffn2, ffn, h, BT, SI_ACT_NONE, h, st))) return rc;
+            if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h2, BT, H, eps, 0, st, h16))) return rc;
+            if ((rc = linear(ctx, Wl.qkv, h2, qkv, BT, SI_ACT_NONE, nullptr, st, h16))) return rc;
+            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16))) return rc;
+            if ((rc = linear(ctx, Wl.out, att, h, BT, SI_ACT_NONE, h, st, att16))) return rc;
+            if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h2, BT, H, eps, 0, st, h16))) return rc;
+            if ((rc = linear(ctx, Wl.ffn1, h2, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16))) return rc;
+            if ((rc = linear(ctx, Wl.ffn2, ffn, h, BT, SI_ACT_NONE, h, st, ffn16))) return rc;
         }
     }
     if (d.stable_layer_norm) {

@@ -87,11 +87,14 @@ int si_launch_conv0_affine(si_ctx* ctx, const WaveNormParams& p, const double* s
 size_t si_conv0_partials_bytes(int B, int N);
 
 // y = LN(x [+ add]) * gamma + beta over the last dim C (rows x C), optional GELU afterwards
+// y16 (optional): bf16 copy of y for a bf16 GEMM consumer
 int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const float* gamma, const float* beta, float* y,
-                        long rows, int C, float eps, int gelu, hipStream_t st);
+                        long rows, int C, float eps, int gelu, hipStream_t st, unsigned short* y16 = nullptr);
 
 // softmax(q k^T / sqrt(64)) v for head_dim 64; qkv (B, T, 3H) packed [q | k | v]; out (B, T, H)
-int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st);
+// out16 (optional): write the result as bf16 there INSTEAD of fp32 into out
+int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st,
+                        unsigned short* out16 = nullptr);
 
 // cosine arg-max against centred centroids + splice of the raw centroid into mel (A10..A13)
 int si_launch_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,

@@ -19,6 +19,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -266,7 +267,8 @@ int si_launch_conv0_affine(si_ctx* ctx, const WaveNormParams& p, const double* s
 template <bool GELU>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float* __restrict__ y, long rows, int C, float eps) {
+                                                        float* __restrict__ y, unsigned short* __restrict__ y16, long rows, int C,
+                                                        float eps) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -309,18 +311,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 o[e] = GELU ? gelu_erf(t) : t;
             }
             *reinterpret_cast<f32x4*>(yr + i) = o;
+            // operand-ready copy for a bf16 GEMM consumer (round-to-nearest-even, as the GEMM's own staging would)
+            if (y16) *reinterpret_cast<bf16x4*>(y16 + row * C + i) = __builtin_convertvector(o, bf16x4);
         }
     }
 }
 
 int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const float* gamma, const float* beta, float* y,
-                        long rows, int C, float eps, int gelu, hipStream_t st) {
+                        long rows, int C, float eps, int gelu, hipStream_t st, unsigned short* y16) {
     if (C % 4 != 0 || C > 2048) return si_fail(ctx, SI_EINVAL, "layernorm width %d must be a multiple of 4 and <= 2048", C);
     if (rows <= 0) return SI_OK;
     dim3 grid((unsigned)((rows + 3) / 4));
     si_prof_begin(ctx, "layernorm", 8.0 * rows * C, 8.0 * rows * C, st);
-    if (gelu) hipLaunchKernelGGL(layernorm_kernel<true>, grid, dim3(256), 0, st, x, add, gamma, beta, y, rows, C, eps);
-    else hipLaunchKernelGGL(layernorm_kernel<false>, grid, dim3(256), 0, st, x, add, gamma, beta, y, rows, C, eps);
+    if (gelu) hipLaunchKernelGGL(layernorm_kernel<true>, grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<false>, grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
@@ -337,7 +341,8 @@ int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const flo
 #define ATT_KT 32
 #define ATT_LD 68     // 64 + 4 floats: 16-B aligned rows, consecutive rows shift by 4 banks
 
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int H,
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                        unsigned short* __restrict__ out16, int T, int H,
                                                         int heads) {
     __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_LD];
     __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * ATT_LD];
@@ -424,24 +429,30 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const int q = q0 + l31;
     if (q < T) {
         const float inv = 1.0f / lrun;
-        float* op = out + ((long)b * T + q) * H + h * 64;
+        const long o = ((long)b * T + q) * H + h * 64;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int d = 8 * g4 + 4 * half;
             f32x4 a = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
             f32x4 c = {o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv};
-            *reinterpret_cast<f32x4*>(op + d) = a;
-            *reinterpret_cast<f32x4*>(op + 32 + d) = c;
+            if (out16) {                 // operand-ready bf16 for the output projection (the only consumer)
+                *reinterpret_cast<bf16x4*>(out16 + o + d) = __builtin_convertvector(a, bf16x4);
+                *reinterpret_cast<bf16x4*>(out16 + o + 32 + d) = __builtin_convertvector(c, bf16x4);
+            } else {
+                *reinterpret_cast<f32x4*>(out + o + d) = a;
+                *reinterpret_cast<f32x4*>(out + o + 32 + d) = c;
+            }
         }
     }
 }
 
-int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st) {
+int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st,
+                        unsigned short* out16) {
     if (heads <= 0 || H != heads * 64) return si_fail(ctx, SI_EINVAL, "attention kernel needs head_dim 64 (H=%d heads=%d)", H, heads);
     if (B <= 0 || T <= 0) return SI_OK;
     dim3 grid((T + 127) / 128, B * heads);
     si_prof_begin(ctx, "attention_f32", 4.0 * B * (double)T * T * H, 16.0 * B * T * H, st);   // 2*T^2*H MACs (QK^T + PV)
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, qkv, out, T, H, heads);
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, qkv, out, out16, T, H, heads);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

@@ -15,7 +15,7 @@ import json
 import re
 import sys
 
-MATH = {"0": "f32", "1": "bf16", "2": "bf16x3"}
+MATH = {"0": "f32", "1": "bf16", "2": "bf16x3", "3": "f16"}
 
 
 def family(kernel_name: str) -> str:

@@ -167,7 +167,9 @@ int si_vocoder_samples(const si_ctx* ctx, int Tm, int stretch);   /* output samp
  * bracketed by two HIP events recorded on the launch stream.  si_profile_stop waits for those events and returns
  * one entry per kernel family: launches, summed device milliseconds, summed ALGORITHMIC flops and bytes (layer
  * shapes only: no padding, halo or recompute).  max_launches bounds the event pool; launches beyond it are not
- * recorded.  This is what bench.py's `roofline` object is computed from. */
+ * recorded.  This is what bench.py's `roofline` object is computed from.  si_profile_filter restricts the bracketing
+ * to ONE family (its entry name; NULL or "" = all): an event pair costs ~4 us of stream time, 6 % of a step when every
+ * launch carries one, so bench.py times its K steps with only the dominant family bracketed. */
 typedef struct si_profile_entry {
     char name[48];
     int32_t launches;
@@ -177,6 +179,7 @@ typedef struct si_profile_entry {
     double bytes;
 } si_profile_entry;
 int si_profile_start(si_ctx* ctx, int max_launches);
+int si_profile_filter(si_ctx* ctx, const char* family);
 int si_profile_stop(si_ctx* ctx, si_profile_entry* out, int capacity, int* count);
 
 /* Test hook.  Intermediates are named "features", "projected", "encoder_in", "last_hidden" (encoder) and

@@ -70,6 +70,7 @@ struct si_ctx {
     // per-launch HIP-event timing (si_profile_start / si_profile_stop)
     struct ProfRec { int name; hipEvent_t a, b; double flops, bytes; };
     bool prof_on = false;
+    std::string prof_filter;             // non-empty: only launches of this kernel family are bracketed
     std::vector<std::string> prof_names;
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
@@ -113,6 +114,7 @@ static int si_tap(si_ctx* ctx, const char* name, const float* src, long n, hipSt
 // Called by every si_launch_* around its kernel; a no-op unless si_profile_start armed it.
 void si_prof_begin(si_ctx* ctx, const char* name, double flops, double bytes, hipStream_t st) {
     if (!ctx->prof_on || ctx->prof_used + 2 > ctx->prof_pool.size()) { ctx->prof_open = -1; return; }
+    if (!ctx->prof_filter.empty() && ctx->prof_filter != name) { ctx->prof_open = -1; return; }
     int id = -1;
     for (size_t i = 0; i < ctx->prof_names.size(); ++i) if (ctx->prof_names[i] == name) { id = (int)i; break; }
     if (id < 0) { id = (int)ctx->prof_names.size(); ctx->prof_names.push_back(name); }
@@ -1085,6 +1087,12 @@ int si_profile_start(si_ctx* ctx, int max_launches) {
     ctx->prof_used = 0;
     ctx->prof_open = -1;
     ctx->prof_on = true;
+    return SI_OK;
+}
+
+int si_profile_filter(si_ctx* ctx, const char* family) {
+    if (!ctx) return SI_EINVAL;
+    ctx->prof_filter = family ? family : "";
     return SI_OK;
 }
 

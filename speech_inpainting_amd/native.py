@@ -23,7 +23,7 @@ SI_MAX_CONV, SI_MAX_UPS, SI_MAX_RB, SI_MAX_DIL = 8, 8, 4, 4
 EXPORTS = ["si_version", "si_create", "si_destroy", "si_last_error", "si_load_weights", "si_alloc_weights",
            "si_weights_device_ptr", "si_workspace_bytes", "si_hubert_forward", "si_codebook_splice",
            "si_codebook_metrics", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
-           "si_vocoder_samples", "si_profile_start", "si_profile_stop",
+           "si_vocoder_samples", "si_profile_start", "si_profile_filter", "si_profile_stop",
            "si_debug_capture", "si_debug_size"]
 
 
@@ -132,6 +132,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.si_debug_size.argtypes = [vp, C.c_char_p]
     lib.si_debug_size.restype = C.c_long
     lib.si_profile_start.argtypes = [vp, i32]
+    lib.si_profile_filter.argtypes = [vp, C.c_char_p]
     lib.si_profile_stop.argtypes = [vp, C.POINTER(ProfileEntry), i32, C.POINTER(i32)]
     for name in EXPORTS:
         if name not in ("si_destroy", "si_last_error", "si_debug_size"):
@@ -317,6 +318,10 @@ class NativeContext:
     # ---- per-kernel HIP-event timing
     def profile_start(self, max_launches: int = 20000):
         self._check(self.lib.si_profile_start(self._h, int(max_launches)), "si_profile_start")
+
+    def profile_filter(self, family: Optional[str]):
+        """Bracket only launches of this kernel family (None: all)."""
+        self._check(self.lib.si_profile_filter(self._h, family.encode() if family else None), "si_profile_filter")
 
     def profile_stop(self):
         """-> list of dicts {name, launches, ms, flops, bytes}; waits for the recorded events."""

@@ -199,7 +199,7 @@ int plan_layout(si_ctx* ctx) {
     int c = C0;
     for (int i = 0; i < d.num_ups; ++i) {
         const int u = d.up_rates[i], k = d.up_kernels[i];
-        L.ups.push_back(P.gemm(vm, 1, k / u, u * (c / 2), c, true));
+        L.ups.push_back(P.gemm(vm, 1, (k + u - 1) / u, u * (c / 2), c, true));   // taps q = j div u; absent (phase, tap) pairs stay zero
         c /= 2;
         for (int j = 0; j < d.num_rb; ++j) {
             ResW r;
@@ -234,11 +234,11 @@ int check_desc(si_ctx* ctx, const si_model_desc* d) {
             return si_fail(ctx, SI_EINVAL, "conv layer %d: dim %d must be a multiple of 16", i, d->conv_dim[i]);
     if (d->hidden_size % 16 || d->intermediate_size % 16) return si_fail(ctx, SI_EINVAL, "hidden / intermediate sizes must be multiples of 16");
     if (d->codebook_dim <= 0 || d->codebook_dim > 128 || d->num_clusters <= 0) return si_fail(ctx, SI_EINVAL, "codebook %dx%d unsupported", d->num_clusters, d->codebook_dim);
-    if (d->codebook_dim != d->num_mels) return si_fail(ctx, SI_EINVAL, "codebook_dim %d != num_mels %d: centroids are mel frames", d->codebook_dim, d->num_mels);
     int c = d->up_initial_channel;
     for (int i = 0; i < d->num_ups; ++i) {
-        if (d->up_kernels[i] % d->up_rates[i] || (d->up_kernels[i] - d->up_rates[i]) % 2)
-            return si_fail(ctx, SI_EINVAL, "upsample %d: kernel %d must be a multiple of rate %d with even difference", i, d->up_kernels[i], d->up_rates[i]);
+        // output length rate * L needs padding (k - u) / 2 exact; k need not be a multiple of u (I_da's 11 / 5)
+        if (d->up_kernels[i] < d->up_rates[i] || (d->up_kernels[i] - d->up_rates[i]) % 2)
+            return si_fail(ctx, SI_EINVAL, "upsample %d: kernel %d must be >= rate %d with an even difference", i, d->up_kernels[i], d->up_rates[i]);
         if (c % 32) return si_fail(ctx, SI_EINVAL, "upsample %d: %d input channels must be a multiple of 32", i, c);
         c /= 2;
     }
@@ -768,6 +768,9 @@ int si_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, const int3
     if (!ctx) return SI_EINVAL;
     if (!ctx->weights_ready) return si_fail(ctx, SI_ESTATE, "si_codebook_splice before weights were loaded");
     if (!feats || !frame_pos || !mel || B <= 0 || Lm < 0) return si_fail(ctx, SI_EINVAL, "si_codebook_splice: NULL / empty argument");
+    if (ctx->d.codebook_dim != ctx->d.num_mels)
+        return si_fail(ctx, SI_EINVAL, "codebook_dim %d != generator input width %d: centroids are not frames of this generator's input",
+                       ctx->d.codebook_dim, ctx->d.num_mels);
     SI_HIP_CHECK(hipSetDevice(ctx->device));
     const Layout& L = ctx->lay;
     return si_launch_codebook_splice(ctx, feats, B, T, ctx->d.codebook_dim, frame_pos, Lm, wf(ctx, L.cb_centered), wf(ctx, L.cb_raw),

@@ -128,3 +128,37 @@ def test_config5_ragged_lengths_are_bucketed_and_match_per_clip_oracle():
             assert got["wave"].shape == tuple(ref["wave"].shape)
             assert torch.equal(got["labels"].cpu(), ref["labels"]), (blind, i)
             assert rms(got["wave"].cpu(), ref["wave"]) <= 1e-4, (blind, i, rms(got["wave"].cpu(), ref["wave"]))
+
+
+def test_ida_style_generator_geometry_matches_oracle():
+    """SURVEY 8(f) row f-2, generator core: the unit-HiFi-GAN shape of I_da/configs/LJSpeech/hubert_lut.json:13-20 --
+    upsample rates (5, 4, 4, 2, 2) with kernels (11, 8, 8, 4, 4) (11 is NOT a multiple of 5: three taps per phase, some
+    of them empty), 384 input channels, 16 channels in the last stage -- through si_hifigan_forward(stretch = 0), against
+    the oracle's generator (I_da/src/models.py:185-199 is the same forward as I_ea/hifi_gan/models.py:107-123)."""
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import InpaintingEngine
+    from speech_inpainting_amd.native import NativeError
+    varch = VocoderArch(upsample_rates=(5, 4, 4, 2, 2), upsample_kernel_sizes=(11, 8, 8, 4, 4), upsample_initial_channel=512,
+                        num_mels=384, sampling_rate=16000)
+    harch = HubertArch.tiny()
+    gsd = synth.synth_generator_state(varch)
+    eng = InpaintingEngine(harch, varch, 20, "cuda:0", "fp32", "fp32").load_state(synth.synth_hubert_state(harch), gsd, synth.synth_codebook(20))
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 384, 23, generator=g) * 0.5                  # 23 frames of 20 ms -> 23 * 320 samples
+    taps = {}
+    ref = R.generator_forward(gsd, varch, x, taps)[:, 0, :]
+    got = eng.vocode(x.cuda(), stretch=False).cpu()
+    assert got.shape == ref.shape == (2, 23 * 320)
+    err, sig = rms(got, ref), rms(ref, torch.zeros_like(ref))
+    print(f"I_da-style generator: waveform rms error {err:.3e} (signal rms {sig:.3f})")
+    assert err <= 1e-4 * max(sig, 1.0) and sig > 1e-3
+    # the mel-codebook splice does not apply to a generator whose input is not an 80-bin mel
+    with pytest.raises((NativeError, AssertionError)):
+        eng.splice(torch.zeros(2, 10, 80, device="cuda"), torch.zeros(2, dtype=torch.int32, device="cuda"), 2,
+                   torch.zeros(2, 384, 23, device="cuda"))
+    # fp16 operand mode on the same shape stays inside the gate
+    eng16 = InpaintingEngine(harch, varch, 20, "cuda:0", "fp32", "fp16").load_state(synth.synth_hubert_state(harch), gsd, synth.synth_codebook(20))
+    got16 = eng16.vocode(x.cuda(), stretch=False).cpu()
+    assert rms(got16, ref) <= 1e-3

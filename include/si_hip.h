@@ -10,6 +10,8 @@
  *                           I_ea/predict.py:164-168,171,184-187 ; I_ea/loss_fn.py:44-47
  *   si_codebook_metrics  <- LossFunction.cos_sim loss + cos_sim_target_labels (row f-4)
  *                           I_ea/loss_fn.py:29-62 ; I_ea/predict.py:171-173
+ *   si_kmeans_assign     <- kmeans_model.predict(feats) (row f-2)   I_da/scripts/inpainting.py:204-205 ;
+ *                           ApplyKmeans.__call__                    I_ea/dataset/km_label.py:20-24
  *   si_mel_frontend      <- 22.05 kHz masking + normalize*0.95 + get_mel
  *                           I_ea/predict.py:99-106 ; I_ea/dataset/mel_dump.py:40-98
  *   si_hifigan_forward   <- extend_mel + Generator.forward     I_ea/hifi_gan/inference_modified.py:16-19 ;
@@ -142,6 +144,14 @@ int si_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, const int3
 int si_codebook_metrics(si_ctx* ctx, const float* feats, int B, int T, const int32_t* frame_pos, int Lm,
                         const int64_t* target_labels, float* loss_terms, float* loss, int64_t* pred_labels,
                         float* cos_pred_target, si_stream_t stream);
+
+/* k-means unit assignment: labels[r] = argmin_k ||feats[r] - centroids[k]||^2, first minimum on
+ * ties -- what `kmeans_model.predict(feats)` returns at I_da/scripts/inpainting.py:204-205 (sklearn minimises
+ * ||c||^2 - 2 x.c) and `ApplyKmeans.__call__` at I_ea/dataset/km_label.py:20-24.  feats device fp32 (rows, D),
+ * centroids device fp32 (K, D) (caller-owned: I_da's unit codebook lives in HuBERT feature space, not in the context),
+ * labels device int64 (rows), sq_dist optional device fp32 (rows).  Needs no weights. */
+int si_kmeans_assign(si_ctx* ctx, const float* feats, int64_t rows, int D, const float* centroids, int K, int64_t* labels,
+                     float* sq_dist, si_stream_t stream);
 
 /* Vocoder: mel (B, D, Tm) -> time-stretch x441/256 -> generator -> wav_out (B, floor(Tm*441/256) * hop).
  * stretch = 0 skips extend_mel (mel already at the generator's frame rate; output (B, Tm * hop)). */

@@ -271,6 +271,15 @@ def codebook_argmax(values: torch.Tensor, centroids: torch.Tensor) -> torch.Tens
     return torch.argmax(sim, dim=1).view(values.shape[:-1])
 
 
+def kmeans_assign(feats: torch.Tensor, centroids: torch.Tensor) -> torch.Tensor:
+    """f-2.  `kmeans_model.predict(feats)` (I_da/scripts/inpainting.py:204-205; sklearn minimises ||c||^2 - 2 x.c, the
+    ||x||^2 term being common) == `ApplyKmeans.__call__` (I_ea/dataset/km_label.py:20-24: x^2 - 2 x C + C^2, argmin).
+    feats (rows, D), centroids (K, D) -> int64 (rows)."""
+    x, c = feats.float(), centroids.float()
+    dist = x.pow(2).sum(1, keepdim=True) - 2 * torch.matmul(x, c.T) + c.pow(2).sum(1)[None, :]
+    return dist.argmin(dim=1)
+
+
 def cos_sim_loss(values: torch.Tensor, labels: torch.Tensor, centroids: torch.Tensor):
     """f-4.  `LossFunction.cos_sim` in full (I_ea/loss_fn.py:29-47): loss = -sum(cos(v, centred target) - 1), pred =
     arg-max labels; plus `cos_sim_target_labels` (:49-62).  values (B, Lm, D), labels (B, Lm) ->

@@ -791,6 +791,14 @@ int si_codebook_metrics(si_ctx* ctx, const float* feats, int B, int T, const int
                                       static_cast<hipStream_t>(stream));
 }
 
+int si_kmeans_assign(si_ctx* ctx, const float* feats, int64_t rows, int D, const float* centroids, int K, int64_t* labels,
+                     float* sq_dist, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!feats || !centroids || !labels || rows < 0) return si_fail(ctx, SI_EINVAL, "si_kmeans_assign: NULL / bad argument");
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    return si_launch_kmeans_assign(ctx, feats, (long)rows, D, centroids, K, labels, sq_dist, static_cast<hipStream_t>(stream));
+}
+
 int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch, float* wav_out, void* workspace,
                        size_t workspace_bytes, si_stream_t stream) {
     if (!ctx) return SI_EINVAL;

@@ -101,6 +101,10 @@ int si_launch_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, int
                               const float* cb_centered /*K x D*/, const float* cb_raw /*K x D*/,
                               const float* cb_rnorm /*K*/, int K, float* mel, int Tm, int64_t* labels, hipStream_t st);
 
+// k-means unit assignment: labels[row] = argmin_k ||x_row - c_k||^2 (first minimum); dist (optional) = that squared distance
+int si_launch_kmeans_assign(si_ctx* ctx, const float* x, long rows, int D, const float* cent, int K, int64_t* labels, float* dist,
+                            hipStream_t st);
+
 // loss half of LossFunction.cos_sim + cos_sim_target_labels (f-4): per-frame terms 1 - cos(v, c_target), their
 // fixed-order sum, arg-max labels and cos(c_pred, c_target)
 int si_launch_codebook_metrics(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,

@@ -597,6 +597,57 @@ int si_launch_codebook_metrics(si_ctx* ctx, const float* feats, int B, int T, in
     return SI_OK;
 }
 
+// k-means unit assignment: label = argmin_k ||x - c_k||^2 = argmin_k (||c_k||^2 - 2 x.c_k), the
+// quantity sklearn's KMeans.predict minimises (I_da/scripts/inpainting.py:204-205 calls it on HuBERT features; same
+// distance as I_ea/dataset/km_label.py:20-24).  One workgroup per row; thread k walks centroid k (L2-resident table).
+__global__ __launch_bounds__(256) void kmeans_assign_kernel(const float* __restrict__ x, int D, const float* __restrict__ cent,
+                                                            int K, int64_t* __restrict__ labels, float* __restrict__ dist) {
+    extern __shared__ float xs[];
+    __shared__ float bs[4];
+    __shared__ int bi[4];
+    const long row = blockIdx.x;
+    const float* xr = x + row * D;
+    float xx = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) { const float v = xr[d]; xs[d] = v; xx = fmaf(v, v, xx); }
+    __syncthreads();
+    float best = INFINITY;
+    int besti = 0x7fffffff;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float* c = cent + (long)k * D;
+        float dot = 0.f, cc = 0.f;
+        for (int d = 0; d < D; ++d) { const float cv = c[d]; dot = fmaf(xs[d], cv, dot); cc = fmaf(cv, cv, cc); }
+        const float s = cc - 2.f * dot;
+        if (s < best) { best = s; besti = k; }                      // ascending k per thread: first minimum wins
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        xx += __shfl_xor(xx, o, 64);
+    }
+    __shared__ float xparts[4];
+    if ((threadIdx.x & 63) == 0) { bs[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; xparts[threadIdx.x >> 6] = xx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float b = bs[0]; int i = bi[0];
+        for (int w = 1; w < 4; ++w) if (bs[w] < b || (bs[w] == b && bi[w] < i)) { b = bs[w]; i = bi[w]; }
+        labels[row] = i;
+        if (dist) dist[row] = b + (xparts[0] + xparts[1] + xparts[2] + xparts[3]);   // squared distance to the winner
+    }
+}
+
+int si_launch_kmeans_assign(si_ctx* ctx, const float* x, long rows, int D, const float* cent, int K, int64_t* labels, float* dist,
+                            hipStream_t st) {
+    if (D <= 0 || D > 8192 || K <= 0) return si_fail(ctx, SI_EINVAL, "kmeans_assign: D=%d (<= 8192) K=%d", D, K);
+    if (rows <= 0) return SI_OK;
+    si_prof_begin(ctx, "kmeans_assign", 2.0 * rows * (double)K * D, 4.0 * rows * D, st);
+    hipLaunchKernelGGL(kmeans_assign_kernel, dim3((unsigned)rows), dim3(256), (size_t)D * sizeof(float), st, x, D, cent, K, labels, dist);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
 int si_launch_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,
                               const float* cb_centered, const float* cb_raw, const float* cb_rnorm, int K, float* mel, int Tm,
                               int64_t* labels, hipStream_t st) {

@@ -22,7 +22,7 @@ SI_MAX_CONV, SI_MAX_UPS, SI_MAX_RB, SI_MAX_DIL = 8, 8, 4, 4
 
 EXPORTS = ["si_version", "si_create", "si_destroy", "si_last_error", "si_load_weights", "si_alloc_weights",
            "si_weights_device_ptr", "si_workspace_bytes", "si_hubert_forward", "si_codebook_splice",
-           "si_codebook_metrics", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
+           "si_codebook_metrics", "si_kmeans_assign", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
            "si_vocoder_samples", "si_profile_start", "si_profile_filter", "si_profile_stop",
            "si_debug_capture", "si_debug_size"]
 
@@ -122,6 +122,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.si_hubert_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_codebook_splice.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp]
     lib.si_codebook_metrics.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp]
+    lib.si_kmeans_assign.argtypes = [vp, vp, C.c_int64, i32, vp, i32, vp, vp, vp]
     lib.si_hifigan_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_mel_frames.argtypes = [i32]
     lib.si_mel_workspace_bytes.argtypes = [vp, i32, i32, C.POINTER(sz)]
@@ -261,6 +262,19 @@ class NativeContext:
         self._check(self.lib.si_codebook_metrics(self._h, _ptr(feats), B, T, _ptr(frame_pos), lm, _ptr(target), _ptr(terms),
                                                  _ptr(loss), _ptr(pred), _ptr(cpt), self._stream()), "si_codebook_metrics")
         return loss, terms, pred, cpt
+
+    def kmeans_assign(self, feats: torch.Tensor, centroids: torch.Tensor, with_distance: bool = False):
+        """feats (..., D), centroids (K, D) -> int64 labels (...) [, squared distance to the winner]."""
+        assert feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous()
+        assert centroids.is_cuda and centroids.dtype == torch.float32 and centroids.is_contiguous() and centroids.dim() == 2
+        D = feats.shape[-1]
+        assert centroids.shape[1] == D
+        rows = feats.numel() // D
+        labels = torch.empty(feats.shape[:-1], dtype=torch.int64, device=self.device)
+        dist = torch.empty(feats.shape[:-1], dtype=torch.float32, device=self.device) if with_distance else None
+        self._check(self.lib.si_kmeans_assign(self._h, _ptr(feats), rows, D, _ptr(centroids), centroids.shape[0], _ptr(labels),
+                                              _ptr(dist), self._stream()), "si_kmeans_assign")
+        return (labels, dist) if with_distance else labels
 
     def hifigan_forward(self, mel: torch.Tensor, stretch: bool = True) -> torch.Tensor:
         assert mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous() and mel.dim() == 3

@@ -89,3 +89,29 @@ def test_too_short_clip_is_refused(ctx):
     from speech_inpainting_amd.native import NativeError
     with pytest.raises((NativeError, ValueError)):
         ctx.mel_frontend(torch.zeros(1, 300, device="cuda"))
+
+
+def test_kmeans_assignment_matches_sklearn_and_oracle(ctx):
+    """f-2: si_kmeans_assign vs sklearn's KMeans.predict (the call the reference makes, I_da/scripts/inpainting.py:204-205)
+    and vs the oracle's restatement of I_ea/dataset/km_label.py:20-24.  Labels must agree wherever the two best
+    centroids are not within fp32 rounding of each other."""
+    from sklearn.cluster import KMeans
+    g = torch.Generator().manual_seed(9)
+    for rows, D, K in ((6368, 768, 100), (500, 80, 500), (7, 1024, 3)):
+        cent = torch.randn(K, D, generator=g)
+        lab_true = torch.randint(0, K, (rows,), generator=g)
+        x = cent[lab_true] + 0.9 * torch.randn(rows, D, generator=g)      # noisy members of known clusters
+        km = KMeans(n_clusters=K, n_init=1)
+        km.cluster_centers_ = cent.numpy().astype(np.float32)
+        km._n_threads = 1
+        ref_sk = torch.from_numpy(km.predict(x.numpy().astype(np.float32))).long()
+        ref_or = R.kmeans_assign(x, cent)
+        got, dist = ctx.kmeans_assign(x.cuda(), cent.cuda(), with_distance=True)
+        got, dist = got.cpu(), dist.cpu()
+        d_all = torch.cdist(x.double(), cent.double()).pow(2)
+        top2 = d_all.topk(2, dim=1, largest=False).values
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-4 * top2[:, 1]
+        assert clear.float().mean() > 0.99
+        assert torch.equal(got[clear], ref_sk[clear]) and torch.equal(got[clear], ref_or[clear]), (rows, D, K)
+        assert torch.equal(got[clear], d_all.argmin(1)[clear])
+        assert torch.allclose(dist.double(), top2[:, 0], rtol=1e-4, atol=1e-3)

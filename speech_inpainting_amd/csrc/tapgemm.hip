@@ -77,8 +77,14 @@ __device__ unsigned long long si_tg_stamps[24];
 // second argument the allocator takes up to 235 VGPRs + 64 accumulators and halves the occupancy.
 // A16: the activations arrive operand-ready (p.x16: 16-bit, already in the MFMA operand type of MATH, prologue
 // activation already applied by the producer's epilogue): staging is an 8-byte copy per 4 channels, no conversion.
+// Occupancy target: 2 waves per SIMD in general.  The operand-ready convolution kernels are light enough for 4 (128 VGPRs:
+// half-width staging registers, per-tile epilogue): two 8-wave / four 4-wave workgroups per CU, so one workgroup's cold
+// prologue and epilogue overlap another's main loop (measured: 256x128 8.8 -> 7.8 ms/step, 256x32 3.3 -> 3.1).  The
+// 256x64 tile spills at 128 registers and loses (4.1 -> 5.0), Linear layers likewise, so both stay at 2.
+template <int BM, int BN, int NT, bool LINEAR, bool A16> struct WavesPerSimd { static constexpr int value = (A16 && !LINEAR && !(BM == 256 && BN == 64 && NT == 256)) ? 4 : 2; };
+
 template <int MATH, int BM, int BN, int WARPS_M, int WARPS_N, int BK, bool LINEAR, bool A16 = false>
-__global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void tapgemm_kernel(const TapGemmParams p) {
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * WARPS_M * WARPS_N, LINEAR, A16>::value)) void tapgemm_kernel(const TapGemmParams p) {
     static_assert(!A16 || MATH == SI_MATH_BF16 || MATH == SI_MATH_F16, "operand-ready activations are 16-bit single-plane");
     static_assert(WARPS_M * WARPS_N == 4 || WARPS_M * WARPS_N == 8, "4 or 8 waves per workgroup");
     constexpr int NT = 64 * WARPS_M * WARPS_N;          // threads per workgroup
@@ -142,7 +148,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void tapgemm_kernel(cons
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
     TG_T(st_begin);
 #endif
-    f32x4 ra[MAXA];                              // activation chunk(s) in flight: one set, or two half-sets (Linear)
+    typedef typename std::conditional<A16, f32x2, f32x4>::type ra_t;   // 4 channels per slot: 8 bytes operand-ready, 16 bytes fp32
+    ra_t ra[MAXA];                               // activation chunk(s) in flight: one set, or two half-sets (Linear)
     f32x4 rb0[PLANES][MAXB], rb1[PLANES][MAXB];  // weight slabs of iterations it+1 / it+2 in flight
 
     // registers [LO, LO+CNT) of `ra` <- chunk c0 of the activation tile (zero outside the clip)
@@ -151,15 +158,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void tapgemm_kernel(cons
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
             const int idx = tid + i * NT;
-            ra[LO + i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[LO + i] = ra_t{};
             if (idx < nA) {
                 const int r = idx / V4, j = idx - r * V4;
                 const int grow = base_in + r;
                 if constexpr (A16) {
-                    if (grow >= 0 && grow < p.Lin) {
-                        const f32x2 t = *reinterpret_cast<const f32x2*>(xs16 + (long)grow * p.ldx + c0 + 4 * j);
-                        ra[LO + i][0] = t[0]; ra[LO + i][1] = t[1];
-                    }
+                    if (grow >= 0 && grow < p.Lin) ra[LO + i] = *reinterpret_cast<const f32x2*>(xs16 + (long)grow * p.ldx + c0 + 4 * j);
                 } else {
                     if (grow >= 0 && grow < p.Lin) ra[LO + i] = *reinterpret_cast<const f32x4*>(xs + (long)grow * p.ldx + c0 + 4 * j);
                 }
@@ -173,11 +177,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void tapgemm_kernel(cons
             const int idx = tid + i * NT;
             if (idx < nA) {
                 const int r = idx / V4, j = idx - r * V4;
-                f32x4 v = ra[LO + i];
                 if constexpr (A16) {
-                    *reinterpret_cast<f32x2*>(dst + r * LD + 4 * j) = f32x2{v[0], v[1]};
+                    *reinterpret_cast<f32x2*>(dst + r * LD + 4 * j) = ra[LO + i];
                     continue;
                 }
+                f32x4 v;
+                if constexpr (!A16) v = ra[LO + i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
                 if constexpr (MATH == SI_MATH_F32) {
@@ -449,53 +454,63 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void tapgemm_kernel(cons
             vb[i][j] = nok ? ((m0 + wm0 + i * 32 + 4 * half) * p.ldo + col) * 4 : (int)0x80000000;
     }
     // C/D row of accumulator register r (besides the 4*half already in vb): (r&3) + 8*(r>>2)
-    float rv[TM][TN][16], ov[TM][TN][16];
-    if (has_res) {
+    // The burst covers the whole wave tile, except in the kernels built for four waves per SIMD (128 VGPRs), which go
+    // through it one 32x32 tile at a time: their co-resident waves cover the round trips.
+    constexpr bool light = WavesPerSimd<BM, BN, NT, LINEAR, A16>::value == 4;
+    constexpr int IG = light ? 1 : TM, JG = light ? 1 : TN;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int i0 = 0; i0 < TM; i0 += IG)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+    for (int j0 = 0; j0 < TN; j0 += JG) {
+        float rv[IG][JG][16], ov[IG][JG][16];
+        if (has_res) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    rv[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, vb[i][j] + ((r & 3) + 8 * (r >> 2)) * rstep, 0, 0));
-    }
-    if (acc_out) {
+            for (int i = 0; i < IG; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < JG; ++j)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                    for (int r = 0; r < 16; ++r)
+                        rv[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, vb[i0 + i][j0 + j] + ((r & 3) + 8 * (r >> 2)) * rstep, 0, 0));
+        }
+        if (acc_out) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    ov[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(orsrc, vb[i][j] + ((r & 3) + 8 * (r >> 2)) * rstep, 0, 0));
-    }
+            for (int i = 0; i < IG; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < JG; ++j)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+                    for (int r = 0; r < 16; ++r)
+                        ov[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(orsrc, vb[i0 + i][j0 + j] + ((r & 3) + 8 * (r >> 2)) * rstep, 0, 0));
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[i][j][r] + bv[j];
-                if (gelu) v = gelu_erf(v);
-                if (has_res) v += rv[i][j][r];
-                v *= p.alpha;
-                if (acc_out) v += ov[i][j][r];
-                const int off = vb[i][j] + ((r & 3) + 8 * (r >> 2)) * rstep;
-                if (has_out) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, off, 0, 0);
-                if constexpr (MATH == SI_MATH_BF16 || MATH == SI_MATH_F16) {
-                    if (has_o16) {      // operand-ready copy for the consumer: its prologue activation, then its operand rounding
-                        float w = v > 0.f ? v : v * slope16;
-                        unsigned short h;
-                        if constexpr (MATH == SI_MATH_F16) {
-                            w = __builtin_fminf(__builtin_fmaxf(w, -65504.f), 65504.f);
-                            h = __builtin_bit_cast(unsigned short, (_Float16)w);
-                        } else {
-                            h = __builtin_bit_cast(unsigned short, (__bf16)w);
+        for (int ii = 0; ii < IG; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < JG; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = i0 + ii, j = j0 + jj;
+                    float v = acc[i][j][r] + bv[j];
+                    if (gelu) v = gelu_erf(v);
+                    if (has_res) v += rv[ii][jj][r];
+                    v *= p.alpha;
+                    if (acc_out) v += ov[ii][jj][r];
+                    const int off = vb[i][j] + ((r & 3) + 8 * (r >> 2)) * rstep;
+                    if (has_out) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, off, 0, 0);
+                    if constexpr (MATH == SI_MATH_BF16 || MATH == SI_MATH_F16) {
+                        if (has_o16) {  // operand-ready copy for the consumer: its prologue activation, then its operand rounding
+                            float w = v > 0.f ? v : v * slope16;
+                            unsigned short h;
+                            if constexpr (MATH == SI_MATH_F16) {
+                                w = __builtin_fminf(__builtin_fmaxf(w, -65504.f), 65504.f);
+                                h = __builtin_bit_cast(unsigned short, (_Float16)w);
+                            } else {
+                                h = __builtin_bit_cast(unsigned short, (__bf16)w);
+                            }
+                            // a masked column carries offset 2^31: halving it would bring it back into range
+                            __builtin_amdgcn_raw_buffer_store_b16(h, hrsrc, vb[i][j] == (int)0x80000000 ? (int)0x80000000 : off / 2, 0, 0);
                         }
-                        // a masked column carries offset 2^31: halving it would bring it back into range
-                        __builtin_amdgcn_raw_buffer_store_b16(h, hrsrc, vb[i][j] == (int)0x80000000 ? (int)0x80000000 : off / 2, 0, 0);
                     }
                 }
-            }
+    }
 #ifdef TG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // include the store drain: a wave cannot retire before it
     TG_T(st_end);
@@ -575,6 +590,14 @@ static int launch_math(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     const int adil = p.dil < 0 ? -p.dil : p.dil;
     const int cap = (p.ntaps == 1 ? MaxA<256>::value / 2 : MaxA<256>::value) * 256;
     const bool tall = ((255 * p.stride + (p.ntaps - 1) * adil + 1) * (BK / 4) <= cap) && p.M > 128;
+    if constexpr (MATH == SI_MATH_F16 || MATH == SI_MATH_BF16) {
+        // operand-ready activations, N = 64: eight light waves (32 rows x 64 columns, 92 VGPRs) per 256-row tile instead
+        // of four heavy ones that spill at the 4-waves-per-SIMD budget (4.32 -> 4.20 ms/step; for N = 32 the 4-wave tile
+        // stays faster: 3.11 vs 3.53)
+        static const int narrow8 = getenv("SI_TG_NARROW8") ? atoi(getenv("SI_TG_NARROW8")) : 1;
+        const bool fits8 = (255 * p.stride + (p.ntaps - 1) * adil + 1) * (BK / 4) <= MaxA<256, 512>::value * 512;
+        if (narrow8 && bn == 64 && p.x16 && p.ntaps > 1 && tall && fits8 && BK == 32) return launch_cfg<MATH, 256, 64, 8, 1, BK>(ctx, p, st);
+    }
     if (bn == 64) return tall ? launch_cfg<MATH, 256, 64, 4, 1, BK>(ctx, p, st) : launch_cfg<MATH, 128, 64, 2, 2, BK>(ctx, p, st);
     return tall ? launch_cfg<MATH, 256, 32, 4, 1, BK>(ctx, p, st) : launch_cfg<MATH, 128, 32, 4, 1, BK>(ctx, p, st);
 }

@@ -661,6 +661,9 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     double* partials = reinterpret_cast<double*>(W.bytes(si_conv0_partials_bytes(B, N)));
     float* affine = W.floats((size_t)B * d.conv_dim[0] * 2);
     float* cbuf[2] = {W.floats((size_t)B * cmax), W.floats((size_t)B * cmax)};
+    static const int enc_opr_env0 = getenv("SI_ENC_OPREADY") ? atoi(getenv("SI_ENC_OPREADY")) : 1;
+    const bool c16 = enc_opr_env0 && d.encoder_math == SI_MATH_BF16 && !d.feat_norm_layer && d.num_conv >= 2;
+    unsigned short* cb16[2] = {reinterpret_cast<unsigned short*>(cbuf[0]), reinterpret_cast<unsigned short*>(cbuf[1])};   // same storage, bf16 view
     float* lnf = W.floats(BT * CF);
     float* h = W.floats(BT * H);
     float* h2 = W.floats(BT * H);
@@ -684,7 +687,10 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     WaveNormParams wp{wav, mask_start, mask_len, B, N, e.L[1], d.conv_dim[0], d.conv_kernel[0], d.conv_stride[0], normalize};
     if ((rc = si_launch_wave_stats(ctx, wp, stats, st))) return rc;
     if (!d.feat_norm_layer) {
-        rc = si_launch_conv0_groupnorm(ctx, wp, stats, wf(ctx, L.conv0_w), wf(ctx, L.conv0_g), wf(ctx, L.conv0_b), partials, affine, cbuf[0], st);
+        // group-norm flavour in bf16 mode: the conv chain runs on operand-ready bf16 activations (conv0 and convs 1..n-2
+        // write ONLY the bf16 operand of their single consumer; the last conv writes fp32 for the LayerNorm that follows)
+        rc = si_launch_conv0_groupnorm(ctx, wp, stats, wf(ctx, L.conv0_w), wf(ctx, L.conv0_g), wf(ctx, L.conv0_b), partials, affine, cbuf[0], st,
+                                       c16 ? cb16[0] : nullptr);
     } else {
         rc = si_launch_conv0_affine(ctx, wp, stats, wf(ctx, L.conv0_w), d.conv_bias ? wf(ctx, L.conv0_bias) : nullptr, affine, cbuf[0], st);
         if (!rc) rc = si_launch_layernorm(ctx, cbuf[0], nullptr, wf(ctx, L.conv0_g), wf(ctx, L.conv0_b), cbuf[0], (long)B * e.L[1], d.conv_dim[0], 1e-5f, 1, st);
@@ -696,6 +702,10 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
         const ConvW& c = L.convs[i - 1];
         TapGemmParams p = gemm_params(ctx, c.g);
         p.x = cbuf[cur]; p.out = cbuf[cur ^ 1];
+        if (c16) {
+            p.x = nullptr; p.x16 = cb16[cur];
+            if (i + 1 < d.num_conv) { p.out = nullptr; p.out16 = cb16[cur ^ 1]; p.out16_slope = 1.f; }
+        }
         p.nseg = B; p.Lin = e.L[i]; p.M = e.L[i + 1]; p.ldx = d.conv_dim[i - 1]; p.x_seg_stride = (long)e.L[i] * d.conv_dim[i - 1];
         p.stride = d.conv_stride[i]; p.ldo = d.conv_dim[i]; p.o_seg_stride = (long)e.L[i + 1] * d.conv_dim[i];
         p.olimit = p.o_seg_stride;

@@ -80,7 +80,7 @@ int si_launch_wave_stats(si_ctx* ctx, const WaveNormParams& p, double* stats /*B
 // conv0 -> GroupNorm(C groups) -> GELU, channels-last out (B, L1, C)
 int si_launch_conv0_groupnorm(si_ctx* ctx, const WaveNormParams& p, const double* stats, const float* w /*[C][K]*/,
                               const float* gamma, const float* beta, double* partials, float* affine, float* out,
-                              hipStream_t st);
+                              hipStream_t st, unsigned short* out16 = nullptr /* write bf16 there INSTEAD of fp32 into out */);
 // conv0 (+bias) only, channels-last out, for the layer-norm flavour (LN+GELU applied by si_launch_layernorm)
 int si_launch_conv0_affine(si_ctx* ctx, const WaveNormParams& p, const double* stats, const float* w, const float* bias,
                            float* affine, float* out, hipStream_t st);

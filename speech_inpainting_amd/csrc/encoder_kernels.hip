@@ -155,7 +155,7 @@ __global__ void conv0_bias_affine_kernel(int B, int C, const float* __restrict__
 template <int K, bool GELU>
 __global__ __launch_bounds__(256) void conv0_apply_kernel(WaveNormParams p, const double* __restrict__ stats,
                                                           const float* __restrict__ w, const float* __restrict__ affine,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, unsigned short* __restrict__ out16) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem);
     const int b = blockIdx.y;
@@ -196,7 +196,9 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(WaveNormParams p, cons
             float v = fmaf(av[e], acc, sv[e]);
             y[e] = GELU ? gelu_erf(v) : v;
         }
-        *reinterpret_cast<f32x4*>(out + ((long)b * p.L1 + t0 + r) * C + c4) = y;
+        // out16: the only consumer is a bf16 GEMM-form conv -- write its operand (half the 26 MB/clip) instead of fp32
+        if (out16) *reinterpret_cast<bf16x4*>(out16 + ((long)b * p.L1 + t0 + r) * C + c4) = __builtin_convertvector(y, bf16x4);
+        else *reinterpret_cast<f32x4*>(out + ((long)b * p.L1 + t0 + r) * C + c4) = y;
     }
 }
 
@@ -223,19 +225,20 @@ int si_launch_wave_stats(si_ctx* ctx, const WaveNormParams& p, double* stats, hi
 }
 
 static int conv0_apply(si_ctx* ctx, const WaveNormParams& p, const double* stats, const float* w, const float* affine,
-                       float* out, bool gelu, hipStream_t st) {
+                       float* out, bool gelu, hipStream_t st, unsigned short* out16 = nullptr) {
     dim3 grid((p.L1 + SI_C0_ROWS - 1) / SI_C0_ROWS, p.B);
     const size_t lds = ((size_t)(SI_C0_ROWS - 1) * p.S + p.K) * sizeof(float);
-    si_prof_begin(ctx, "conv0_apply", 2.0 * p.B * p.L1 * (double)p.C * p.K, 4.0 * p.B * ((double)p.N + (double)p.L1 * p.C), st);
-    if (gelu) hipLaunchKernelGGL((conv0_apply_kernel<10, true>), grid, dim3(256), lds, st, p, stats, w, affine, out);
-    else hipLaunchKernelGGL((conv0_apply_kernel<10, false>), grid, dim3(256), lds, st, p, stats, w, affine, out);
+    si_prof_begin(ctx, "conv0_apply", 2.0 * p.B * p.L1 * (double)p.C * p.K, p.B * (4.0 * p.N + (out16 ? 2.0 : 4.0) * p.L1 * p.C), st);
+    if (gelu) hipLaunchKernelGGL((conv0_apply_kernel<10, true>), grid, dim3(256), lds, st, p, stats, w, affine, out, out16);
+    else hipLaunchKernelGGL((conv0_apply_kernel<10, false>), grid, dim3(256), lds, st, p, stats, w, affine, out, out16);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
 }
 
 int si_launch_conv0_groupnorm(si_ctx* ctx, const WaveNormParams& p, const double* stats, const float* w, const float* gamma,
-                              const float* beta, double* partials, float* affine, float* out, hipStream_t st) {
+                              const float* beta, double* partials, float* affine, float* out, hipStream_t st,
+                              unsigned short* out16) {
     int rc = conv0_check(ctx, p);
     if (rc) return rc;
     const int nchunks = (p.L1 + SI_C0_TCH - 1) / SI_C0_TCH;
@@ -248,7 +251,7 @@ int si_launch_conv0_groupnorm(si_ctx* ctx, const WaveNormParams& p, const double
     hipLaunchKernelGGL(conv0_gn_affine_kernel, dim3(p.B), dim3(256), 0, st, p, partials, nchunks, w, gamma, beta, affine);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
-    return conv0_apply(ctx, p, stats, w, affine, out, true, st);
+    return conv0_apply(ctx, p, stats, w, affine, out, true, st, out16);
 }
 
 // plain flavour with an explicit affine scratch (used by the layer-norm feature extractor)

@@ -80,8 +80,8 @@ __device__ unsigned long long si_tg_stamps[24];
 // Occupancy target: 2 waves per SIMD in general.  The operand-ready convolution kernels are light enough for 4 (128 VGPRs:
 // half-width staging registers, per-tile epilogue): two 8-wave / four 4-wave workgroups per CU, so one workgroup's cold
 // prologue and epilogue overlap another's main loop (measured: 256x128 8.8 -> 7.8 ms/step, 256x32 3.3 -> 3.1).  The
-// 256x64 tile spills at 128 registers and loses (4.1 -> 5.0), Linear layers likewise, so both stay at 2.
-template <int BM, int BN, int NT, bool LINEAR, bool A16> struct WavesPerSimd { static constexpr int value = (A16 && !LINEAR && !(BM == 256 && BN == 64 && NT == 256)) ? 4 : 2; };
+// 4-wave 256x64 and 128x128 tiles spill at 128 registers and lose (4.1 -> 5.0), Linear layers likewise: they stay at 2.
+template <int BM, int BN, int NT, bool LINEAR, bool A16> struct WavesPerSimd { static constexpr int value = (A16 && !LINEAR && !(BM == 256 && BN == 64 && NT == 256) && !(BM == 128 && BN == 128 && NT == 256)) ? 4 : 2; };
 
 template <int MATH, int BM, int BN, int WARPS_M, int WARPS_N, int BK, bool LINEAR, bool A16 = false>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * WARPS_M * WARPS_N, LINEAR, A16>::value)) void tapgemm_kernel(const TapGemmParams p) {

@@ -580,6 +580,12 @@ static int launch_math(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
         static const int big = getenv("SI_TG_BIG") ? atoi(getenv("SI_TG_BIG")) : 1;
         const int adil8 = p.dil < 0 ? -p.dil : p.dil;
         const int cap8 = (p.ntaps == 1 ? MaxA<256, 512>::value / 2 : MaxA<256, 512>::value) * 512;
+        if constexpr (MATH == SI_MATH_F16 || MATH == SI_MATH_BF16) {
+            // operand-ready Linear layers (the encoder's GEMMs): eight light waves (32 x 64 each, 109 VGPRs) per 128x128
+            // tile instead of four 64x64 ones (211 VGPRs) -- twice the resident waves per CU; 2.83 vs 3.12 ms/step
+            static const int lin8 = getenv("SI_TG_LIN8") ? atoi(getenv("SI_TG_LIN8")) : 1;
+            if (lin8 && p.x16 && p.ntaps == 1 && BK == 32 && p.M > 256) return launch_cfg<MATH, 128, 128, 4, 2, BK>(ctx, p, st);
+        }
         if (big && BK == 32 && p.M > 256 && (255 * p.stride + (p.ntaps - 1) * adil8 + 1) * (BK / 4) <= cap8)
             return launch_cfg<MATH, 256, 128, 4, 2, BK>(ctx, p, st);
         return launch_cfg<MATH, 128, 128, 2, 2, BK>(ctx, p, st);

@@ -588,6 +588,13 @@ static int launch_math(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
         }
         if (big && BK == 32 && p.M > 256 && (255 * p.stride + (p.ntaps - 1) * adil8 + 1) * (BK / 4) <= cap8)
             return launch_cfg<MATH, 256, 128, 4, 2, BK>(ctx, p, st);
+        if constexpr (MATH == SI_MATH_F16 || MATH == SI_MATH_BF16) {
+            // operand-ready convolutions whose halo rules out the 256-row tile (the encoder's stride-2 convs): light waves too
+            static const int conv8 = getenv("SI_TG_CONV8") ? atoi(getenv("SI_TG_CONV8")) : 1;
+            if (conv8 && p.x16 && p.ntaps > 1 && BK == 32 && p.M > 256 &&
+                (127 * p.stride + (p.ntaps - 1) * adil8 + 1) * (BK / 4) <= MaxA<128, 512>::value * 512)
+                return launch_cfg<MATH, 128, 128, 4, 2, BK>(ctx, p, st);
+        }
         return launch_cfg<MATH, 128, 128, 2, 2, BK>(ctx, p, st);
     }
     // narrow N: 256-row tiles unless their halo'd activation tile would not fit the prefetch registers

@@ -53,6 +53,7 @@ struct TapGemmParams {
     float alpha;           // v = (acc + bias -> act -> + res) * alpha
     int accumulate;        // out = v + out
     double algo_macs;      // algorithmic multiply-accumulates of the layer (0: derive from the GEMM shape)
+    int xcd_remap;         // set by the launcher: XCD-aware workgroup-id -> tile order
 };
 
 // N-tile width the launcher uses for a given N; the packer pads W rows to a multiple of it.

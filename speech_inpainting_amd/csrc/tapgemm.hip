@@ -111,10 +111,19 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
     // N-tiles of one M-tile are adjacent in dispatch order: they read the same activation rows, so all but the
     // first find them in L2 / Infinity Cache instead of HBM.
     const int ntn = (p.N + BN - 1) / BN;
-    const int mt = blockIdx.x / ntn;
+    // XCD-aware tile order.  Workgroup ids are dealt round-robin over the 8 XCDs (ids b and b + 8 share an L2), so with
+    // the plain id -> tile map the N-tiles of one M-tile, and M-tiles that share halo rows, sit behind eight different
+    // L2s and each fetches the shared rows again (PMC: 2.8x the algorithmic bytes on the encoder GEMMs).  The optional
+    // remap (launcher, SI_TG_XCD=1) gives every XCD label a CONTIGUOUS range of tiles (bijective for any grid size).
+    int tile = blockIdx.x;
+    if (p.xcd_remap) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = tile & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (tile >> 3);
+    }
+    const int mt = tile / ntn;
     const int seg = mt / mtiles;
     const int m0 = (mt % mtiles) * BM;
-    const int n0 = (blockIdx.x % ntn) * BN;
+    const int n0 = (tile % ntn) * BN;
     const int g = blockIdx.y;
 
     const int adil = p.dil < 0 ? -p.dil : p.dil;
@@ -564,8 +573,13 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     const double outs = (double)p.M * p.N * p.groups;
     double bytes = p.nseg * ((a16 ? 2.0 : 4.0) * p.Lin * p.Cin * p.groups + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0) + (p.accumulate ? 4 : 0))) +
                    (double)p.groups * p.ntaps * p.N * p.Cin * (MATH == SI_MATH_F32 || MATH == SI_MATH_BF16X3 ? 4 : 2);
+    // SI_TG_XCD=1 enables the XCD-aware tile order.  Measured: no gain on any family (encoder GEMMs 4.03 vs 4.08 ms/step,
+    // narrow vocoder stages 3.21 vs 3.11): the re-fetched rows come out of the 256 MB Infinity Cache, not HBM.  Off.
+    static const int xcd_env = getenv("SI_TG_XCD") ? atoi(getenv("SI_TG_XCD")) : 0;
+    TapGemmParams pk = p;
+    pk.xcd_remap = xcd_env && grid.x >= 16;
     si_prof_begin(ctx, name, 2.0 * macs, bytes, st);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, pk);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

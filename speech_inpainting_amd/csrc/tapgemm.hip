@@ -55,7 +55,7 @@ template <> struct LdsElem<SI_MATH_F16> { typedef unsigned short type; static co
 // float4 of the activation tile a thread holds in flight: 10 covers 128-row tiles (<= 320 rows at BK = 32),
 // 12 the 256-row tiles (306 rows) and the positional conv (383 rows at BK = 16)
 // (an 8-wave workgroup spreads the same tile over 512 threads: half the registers per thread)
-template <int BM, int NT = 256> struct MaxA { static constexpr int value = NT == 512 ? 6 : (BM == 128 ? 10 : 12); };
+template <int BM, int NT = 256, int BK = 32> struct MaxA { static constexpr int value = BK == 64 ? 8 : (NT == 512 ? 6 : (BM == 128 ? 10 : 12)); };
 
 template <int V> using ic = std::integral_constant<int, V>;
 
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
     constexpr int V4 = BK / 4;                           // float4 per activation row
     constexpr int VB = (MATH == SI_MATH_F32) ? BK / 4 : BK / 8;     // 16-byte vectors per weight row (per plane)
     constexpr int MAXB = (BN * VB + NT - 1) / NT;          // 16-byte vectors of a weight slab per thread (per plane)
-    constexpr int MAXA = MaxA<BM, NT>::value;
+    constexpr int MAXA = MaxA<BM, NT, BK>::value;
     constexpr int HALF = MAXA / 2;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -539,7 +539,7 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     constexpr int LD = BK + LdsElem<MATH>::PAD;
     constexpr int PLANES = (MATH == SI_MATH_BF16X3) ? 2 : 1;
     constexpr int NT = 64 * WARPS_M * WARPS_N;
-    constexpr int MAXA = MaxA<BM, NT>::value;
+    constexpr int MAXA = MaxA<BM, NT, BK>::value;
     const int adil = p.dil < 0 ? -p.dil : p.dil;
     const int rowsA = (BM - 1) * p.stride + (p.ntaps - 1) * adil + 1;
     const int cap = (p.ntaps == 1 ? MAXA / 2 : MAXA) * NT;
@@ -598,7 +598,12 @@ static int launch_math(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
             // operand-ready Linear layers (the encoder's GEMMs): eight light waves (32 x 64 each, 109 VGPRs) per 128x128
             // tile instead of four 64x64 ones (211 VGPRs) -- twice the resident waves per CU; 2.83 vs 3.12 ms/step
             static const int lin8 = getenv("SI_TG_LIN8") ? atoi(getenv("SI_TG_LIN8")) : 1;
-            if (lin8 && p.x16 && p.ntaps == 1 && BK == 32 && p.M > 256) return launch_cfg<MATH, 128, 128, 4, 2, BK>(ctx, p, st);
+            if (lin8 && p.x16 && p.ntaps == 1 && BK == 32 && p.M > 256) {
+                // 64-deep K chunks when K allows: half the iterations (barriers, waits) per tile
+                static const int bk64 = getenv("SI_TG_BK64") ? atoi(getenv("SI_TG_BK64")) : 1;
+                if (bk64 && p.Cin % 64 == 0) return launch_cfg<MATH, 128, 128, 4, 2, 64>(ctx, p, st);
+                return launch_cfg<MATH, 128, 128, 4, 2, BK>(ctx, p, st);
+            }
         }
         if (big && BK == 32 && p.M > 256 && (255 * p.stride + (p.ntaps - 1) * adil8 + 1) * (BK / 4) <= cap8)
             return launch_cfg<MATH, 256, 128, 4, 2, BK>(ctx, p, st);

@@ -130,7 +130,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
     const int dil_lo = p.dil < 0 ? (p.ntaps - 1) * p.dil : 0;
     const int base_in = m0 * p.stride - p.pad + dil_lo;          // input row held in LDS row 0
     const int rowsA = (BM - 1) * p.stride + (p.ntaps - 1) * adil + 1;
-    const int nA = rowsA * V4;                                    // float4 in one activation tile
     const int ntaps = p.ntaps;
     constexpr bool linear = LINEAR;
     const int abufs = linear ? 2 : 1;
@@ -161,31 +160,35 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
     ra_t ra[MAXA];                               // activation chunk(s) in flight: one set, or two half-sets (Linear)
     f32x4 rb0[PLANES][MAXB], rb1[PLANES][MAXB];  // weight slabs of iterations it+1 / it+2 in flight
 
+    // Operand loads go through buffer descriptors: a thread keeps ONE byte offset per operand and adds a compile-time
+    // multiple of a wave-uniform step per slot; rows before / after the segment (negative offset = huge unsigned, or
+    // >= num_records) fail the hardware range check and read as zero.  No 64-bit address registers, no zero-init and no
+    // branch per slot -- with pointer loads the compiler spilled addresses and drained vmcnt(0) around the reloads and
+    // around every predicated slot, several times per K chunk.
+    constexpr int AESZ = A16 ? 2 : 4;
+    const void* const xbase = A16 ? static_cast<const void*>(xs16) : static_cast<const void*>(xs);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(xbase), 0, (int)(((long)p.Lin * p.ldx - (long)g * p.Cin) * AESZ), 0x00020000);
+    static_assert(NT % V4 == 0, "slot i of a thread is row r0 + i * (NT / V4), same column group");
+    const int a_r0 = tid / V4, a_j = tid - a_r0 * V4;
+    const int a_voff = ((base_in + a_r0) * p.ldx + 4 * a_j) * AESZ;
+    const int a_step = (NT / V4) * p.ldx * AESZ;
     // registers [LO, LO+CNT) of `ra` <- chunk c0 of the activation tile (zero outside the clip)
     auto issueA = [&](auto lo, auto cnt, int c0) {
         constexpr int LO = decltype(lo)::value, CNT = decltype(cnt)::value;
+        const int coff = c0 * AESZ;
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
-            const int idx = tid + i * NT;
-            ra[LO + i] = ra_t{};
-            if (idx < nA) {
-                const int r = idx / V4, j = idx - r * V4;
-                const int grow = base_in + r;
-                if constexpr (A16) {
-                    if (grow >= 0 && grow < p.Lin) ra[LO + i] = *reinterpret_cast<const f32x2*>(xs16 + (long)grow * p.ldx + c0 + 4 * j);
-                } else {
-                    if (grow >= 0 && grow < p.Lin) ra[LO + i] = *reinterpret_cast<const f32x4*>(xs + (long)grow * p.ldx + c0 + 4 * j);
-                }
-            }
+            if constexpr (A16) ra[LO + i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, a_voff + i * a_step + coff, 0, 0));
+            else ra[LO + i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, a_voff + i * a_step + coff, 0, 0));
         }
     };
     auto storeA = [&](auto lo, auto cnt, elem_t* dst) {
         constexpr int LO = decltype(lo)::value, CNT = decltype(cnt)::value;
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
-            const int idx = tid + i * NT;
-            if (idx < nA) {
-                const int r = idx / V4, j = idx - r * V4;
+            const int r = a_r0 + i * (NT / V4), j = a_j;
+            if (r < rowsA) {
                 if constexpr (A16) {
                     *reinterpret_cast<f32x2*>(dst + r * LD + 4 * j) = ra[LO + i];
                     continue;
@@ -213,31 +216,30 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
             }
         }
     };
+    const int w_bytes = (int)(sizeof(elem_t) * (size_t)p.groups * wplane);
+    const __amdgpu_buffer_rsrc_t wrsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(PLANES == 2 ? p.w_lo : p.w), 0, w_bytes, 0x00020000);
+    static_assert(NT % VB == 0, "slot i of a thread is slab row r0 + i * (NT / VB), same 16-byte column");
+    const int b_r0 = tid / VB, b_j = tid - b_r0 * VB;
+    const int b_step = (int)sizeof(elem_t) * (NT / VB) * p.Cin;
+    // threads beyond the slab (narrow tiles: BN * VB < NT) load out of range (zero, never stored)
+    const int b_voff = (BN * VB % NT == 0 || tid < BN * VB) ? (int)sizeof(elem_t) * b_r0 * p.Cin + 16 * b_j : (int)0x80000000;
     auto issueB = [&](f32x4 (&rb)[PLANES][MAXB], int c0, int tap) {
+        const int soff = (int)(sizeof(elem_t) * ((size_t)g * wplane + ((size_t)tap * p.Npad + n0) * p.Cin + c0));
 #pragma unroll
-        for (int pl = 0; pl < PLANES; ++pl) {
-            const char* wbase = reinterpret_cast<const char*>(pl == 0 ? p.w : p.w_lo) +
-                                sizeof(elem_t) * ((size_t)g * wplane + ((size_t)tap * p.Npad + n0) * p.Cin + c0);
+        for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
-            for (int i = 0; i < MAXB; ++i) {
-                const int idx = tid + i * NT;
-                if (BN * VB % NT == 0 || idx < BN * VB) {
-                    const int r = idx / VB, j = idx - r * VB;
-                    rb[pl][i] = *reinterpret_cast<const f32x4*>(wbase + sizeof(elem_t) * (size_t)r * p.Cin + 16 * j);
-                }
-            }
-        }
+            for (int i = 0; i < MAXB; ++i)
+                rb[pl][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pl == 0 ? wrsrc0 : wrsrc1, b_voff + i * b_step, soff, 0));
     };
     auto storeB = [&](const f32x4 (&rb)[PLANES][MAXB], elem_t* dst) {
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl)
 #pragma unroll
             for (int i = 0; i < MAXB; ++i) {
-                const int idx = tid + i * NT;
-                if (BN * VB % NT == 0 || idx < BN * VB) {
-                    const int r = idx / VB, j = idx - r * VB;
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(dst + (size_t)pl * BN * LD + r * LD) + 16 * j) = rb[pl][i];
-                }
+                const int r = b_r0 + i * (NT / VB);
+                if (BN * VB % NT == 0 || r < BN)
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(dst + (size_t)pl * BN * LD + r * LD) + 16 * b_j) = rb[pl][i];
             }
     };
 

@@ -39,6 +39,7 @@ MASK_FRAMES = 10          # 200 ms
 GFLOP_PER_CLIP = 268.3    # algorithmic, BASELINE.md section 2
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0, "f16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks
 MFMA_PER_PRODUCT = {"f32": 1, "bf16": 1, "bf16x3": 3, "f16": 1}
+PEAK_HBM_GBS = 8000.0                                             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def log(*a):
@@ -103,13 +104,27 @@ def roofline_of(prof, steps, table=None, table_steps=0):
         tab, table_steps, tot = prof, steps, sum(e["ms"] for e in prof)
     m = family_math(d["name"])
     avg_ms = d["ms"] / d["launches"]
-    ach = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+    ach = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12                    # algorithmic TFLOP/s
+    ach_bw = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9                   # algorithmic GB/s
     traffic, tsrc = measured_traffic(d["name"])
-    roof = {"bound": "mfma", "kernel": d["name"], "achieved": round(ach, 2), "peak": PEAK_TFLOPS[m], "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_TFLOPS[m], 4), "traffic": traffic, "traffic_source": tsrc,
+    # which roof bounds this kernel: arithmetic intensity (algorithmic flop per algorithmic HBM byte) against the ridge
+    # point of its MFMA peak and the 8 TB/s HBM peak
+    intensity = d["flops"] / d["bytes"] if d["bytes"] else float("inf")
+    ridge = PEAK_TFLOPS[m] * 1e12 / (PEAK_HBM_GBS * 1e9)
+    hbm_bound = intensity < ridge
+    roof = {"bound": "hbm" if hbm_bound else "mfma", "kernel": d["name"],
+            "achieved": round(ach_bw if hbm_bound else ach, 2), "peak": PEAK_HBM_GBS if hbm_bound else PEAK_TFLOPS[m],
+            "unit": "GB/s" if hbm_bound else "TFLOP/s",
+            "frac": round(ach_bw / PEAK_HBM_GBS if hbm_bound else ach / PEAK_TFLOPS[m], 4),
+            "traffic": traffic, "traffic_source": tsrc,
             "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+            "flops_per_launch": d["flops"] / d["launches"],
+            "arithmetic_intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
             "avg_launch_ms": round(avg_ms, 4), "launches_per_step": round(d["launches"] / steps, 1),
-            "share_of_kernel_time": round(d["ms"] / tot, 3), "flops_per_launch": d["flops"] / d["launches"],
+            "share_of_kernel_time": round(d["ms"] / tot, 3),
+            "other_roof": {"bound": "mfma" if hbm_bound else "hbm", "achieved": round(ach if hbm_bound else ach_bw, 2),
+                           "peak": PEAK_TFLOPS[m] if hbm_bound else PEAK_HBM_GBS, "unit": "TFLOP/s" if hbm_bound else "GB/s",
+                           "frac": round(ach / PEAK_TFLOPS[m] if hbm_bound else ach_bw / PEAK_HBM_GBS, 4)},
             "mfma_issued_per_product": MFMA_PER_PRODUCT[m],
             "frac_of_mfma_issue_peak": round(ach * MFMA_PER_PRODUCT[m] / PEAK_TFLOPS[m], 4)}
     fams = [{"name": e["name"], "ms_per_step": round(e["ms"] / table_steps, 3),

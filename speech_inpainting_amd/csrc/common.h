@@ -54,6 +54,7 @@ struct TapGemmParams {
     int accumulate;        // out = v + out
     double algo_macs;      // algorithmic multiply-accumulates of the layer (0: derive from the GEMM shape)
     int xcd_remap;         // set by the launcher: XCD-aware workgroup-id -> tile order
+    int wide_epilogue;     // set by the launcher: row-contiguous 16-byte epilogue through an LDS transpose
 };
 
 // N-tile width the launcher uses for a given N; the packer pads W rows to a multiple of it.

@@ -31,6 +31,7 @@
 //   BF16   v_mfma_f32_32x32x16_bf16: lane supplies 8 consecutive k (16 B) of row l&31, k block l>>5.
 //   BF16X3 same instruction three times (lo*hi + hi*lo + hi*hi) for ~fp32 accuracy at 3/16 of the fp32 cost.
 // LDS rows are padded by 16 B so the 16 rows a ds_read_b128 lane group touches fall on distinct 4-bank slots.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -40,6 +41,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -464,10 +467,68 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
         for (int i = 0; i < TM; ++i)
             vb[i][j] = nok ? ((m0 + wm0 + i * 32 + 4 * half) * p.ldo + col) * 4 : (int)0x80000000;
     }
+    constexpr bool light = WavesPerSimd<BM, BN, NT, LINEAR, A16>::value == 4;
+    // Row-contiguous epilogue (the 4-waves-per-SIMD kernels, when columns come in aligned groups of four): each 32x32
+    // accumulator tile is transposed through a private 4.5 KB LDS patch so that a lane owns four CONSECUTIVE columns of
+    // one output row -- residual / accumulate reads and stores are 16 bytes per lane, 8 lanes per 128-byte row segment,
+    // 4 wave-instructions per tile and stream instead of 16 per-lane scalars (and 8-byte stores for the 16-bit copy).
+    if constexpr (light) {
+        if (p.wide_epilogue) {
+            __syncthreads();                                       // every wave is done with the operand tiles in LDS
+            float* const tl = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+            const int lr = lane >> 3, lc = (lane & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn0 + j * 32 + lc;          // first of this lane's four columns
+                    const bool nok = n < p.N;
+                    const f32x4 b4 = (p.bias && nok) ? *reinterpret_cast<const f32x4*>(p.bias + g * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tl[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = acc[i][j][r];
+                    const int obase = nok ? ((m0 + wm0 + i * 32 + lr) * p.ldo + g * p.N + n + (int)p.ooff) * 4 : (int)0x80000000;
+#pragma unroll
+                    for (int q0 = 0; q0 < 4; q0 += 2) {
+                        f32x4 a[2], rr[2], oo[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int off = nok ? obase + (q0 + u) * 8 * rstep : (int)0x80000000;
+                            a[u] = *reinterpret_cast<const f32x4*>(tl + (lr + 8 * (q0 + u)) * 36 + lc);
+                            if (has_res) rr[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0));
+                            if (acc_out) oo[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, off, 0, 0));
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int off = nok ? obase + (q0 + u) * 8 * rstep : (int)0x80000000;
+                            f32x4 v;
+                            f16x4 h16;
+                            bf16x4 b16;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float x = a[u][e] + b4[e];
+                                if (gelu) x = gelu_erf(x);
+                                if (has_res) x += rr[u][e];
+                                x *= p.alpha;
+                                if (acc_out) x += oo[u][e];
+                                v[e] = x;
+                                float w = x > 0.f ? x : x * slope16;
+                                if constexpr (MATH == SI_MATH_F16) h16[e] = (_Float16)__builtin_fminf(__builtin_fmaxf(w, -65504.f), 65504.f);
+                                else b16[e] = (__bf16)w;
+                            }
+                            if (has_out) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off, 0, 0);
+                            if (has_o16) {
+                                const u32x2 pk = MATH == SI_MATH_F16 ? __builtin_bit_cast(u32x2, h16) : __builtin_bit_cast(u32x2, b16);
+                                __builtin_amdgcn_raw_buffer_store_b64(pk, hrsrc, nok ? off / 2 : (int)0x80000000, 0, 0);
+                            }
+                        }
+                    }
+                }
+            return;
+        }
+    }
     // C/D row of accumulator register r (besides the 4*half already in vb): (r&3) + 8*(r>>2)
     // The burst covers the whole wave tile, except in the kernels built for four waves per SIMD (128 VGPRs), which go
     // through it one 32x32 tile at a time: their co-resident waves cover the round trips.
-    constexpr bool light = WavesPerSimd<BM, BN, NT, LINEAR, A16>::value == 4;
     constexpr int IG = light ? 1 : TM, JG = light ? 1 : TN;
 #pragma unroll
     for (int i0 = 0; i0 < TM; i0 += IG)
@@ -549,10 +610,16 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
         return si_fail(ctx, SI_EINVAL, "tapgemm: activation tile of %d rows exceeds the prefetch registers (stride %d, taps %d, dil %d)",
                        rowsA, p.stride, p.ntaps, p.dil);
     const int abufs = p.ntaps == 1 ? 2 : 1;
-    const size_t lds = (size_t)PLANES * ((size_t)abufs * rowsA + 2 * BN) * LD * sizeof(elem_t);
+    size_t lds = (size_t)PLANES * ((size_t)abufs * rowsA + 2 * BN) * LD * sizeof(elem_t);
     if (lds > 160 * 1024) return si_fail(ctx, SI_EINVAL, "tapgemm: LDS tile of %zu bytes exceeds 160 KiB", lds);
     const bool lin = p.ntaps == 1;
     const bool a16 = p.x16 != nullptr;
+    // row-contiguous epilogue of the 4-waves-per-SIMD kernels: needs columns in aligned groups of four and a 4.5 KB LDS
+    // patch per wave (the operand tiles are dead by then)
+    static const int wide_env = getenv("SI_TG_WIDE_EPI") ? atoi(getenv("SI_TG_WIDE_EPI")) : 1;
+    constexpr bool light_cfg = WavesPerSimd<BM, BN, NT, false, true>::value == 4;
+    const bool wide = wide_env && light_cfg && a16 && !lin && p.N % 4 == 0 && p.ldo % 4 == 0 && p.ooff % 4 == 0;
+    if (wide) lds = std::max(lds, (size_t)(NT / 64) * 32 * 36 * sizeof(float));
     void (*kern)(const TapGemmParams) = lin ? tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK, true> : tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK, false>;
     if constexpr (MATH == SI_MATH_BF16 || MATH == SI_MATH_F16) {
         if (a16) kern = lin ? tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK, true, true> : tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK, false, true>;
@@ -580,6 +647,7 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     static const int xcd_env = getenv("SI_TG_XCD") ? atoi(getenv("SI_TG_XCD")) : 0;
     TapGemmParams pk = p;
     pk.xcd_remap = xcd_env && grid.x >= 16;
+    pk.wide_epilogue = wide;
     si_prof_begin(ctx, name, 2.0 * macs, bytes, st);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, pk);
     si_prof_end(ctx, st);

@@ -852,6 +852,13 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
     // 20-40 % less HBM / L2 traffic on the convolution inputs.  SI_VOC_OPREADY=0 restores the fp32-input path.
     static const int opready_env = getenv("SI_VOC_OPREADY") ? atoi(getenv("SI_VOC_OPREADY")) : 1;
     const bool opr = opready_env && (d.vocoder_math == SI_MATH_BF16 || d.vocoder_math == SI_MATH_F16);
+    // fp16 activation stream (fp16 mode): activations live ONLY as raw fp16 -- the residual stream too -- and the
+    // consumer applies its leaky-ReLU to the packed halves while staging: 10 instead of 16 bytes of HBM traffic per
+    // element and conv pair (these stages run on the memory side in fp16).  The rounding it adds (fp16 after every
+    // residual add) is small next to the operand rounding the mode already has: waveform RMS error 1.35e-4 vs 1.10e-4
+    // (gate 1e-3).  SI_VOC_RES16=0 keeps the fp32 residual stream.
+    static const int res16_env = getenv("SI_VOC_RES16") ? atoi(getenv("SI_VOC_RES16")) : 1;
+    const bool r16 = opr && res16_env && d.vocoder_math == SI_MATH_F16;
     if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: vocoder workspace carve exceeded its own estimate");
     if (nstr == 2 && !ctx->aux_stream) {
         SI_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
@@ -874,7 +881,8 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
         {
             TapGemmParams p = gemm_params(ctx, Ly.pre);
             p.x = ext; p.out = x;
-            if (opr) { p.out16 = x16; p.out16_slope = 0.1f; }
+            if (opr) { p.out16 = x16; p.out16_slope = r16 ? 1.f : 0.1f; }
+            if (r16) p.out = nullptr;
             p.nseg = Bc; p.Lin = (int)Tout; p.M = (int)Tout; p.ldx = Ly.mel_ld; p.x_seg_stride = Tout * Ly.mel_ld;
             p.algo_macs = (double)Bc * Tout * d.up_initial_channel * (double)d.num_mels * 7;
             p.pad = 3; p.ldo = d.up_initial_channel; p.o_seg_stride = Tout * d.up_initial_channel; p.olimit = p.o_seg_stride;
@@ -889,14 +897,15 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
             {
                 TapGemmParams p = gemm_params(ctx, Ly.ups[i]);
                 p.x = x; p.out = U;
-                if (opr) { p.x = nullptr; p.x16 = x16; p.out16 = U16; p.out16_slope = 0.1f; }
+                if (opr) { p.x = nullptr; p.x16 = x16; p.out16 = U16; p.out16_slope = r16 ? 1.f : 0.1f; }
+                if (r16) p.out = nullptr;
                 p.nseg = Bc; p.Lin = (int)Lc; p.M = (int)((pad + Lo - 1) / u + 1); p.ldx = c; p.x_seg_stride = Lc * c;
                 p.dil = -1; p.ldo = u * cout; p.o_seg_stride = Lo * cout; p.ooff = -(long)pad * cout; p.olimit = Lo * cout;
-                p.pro_slope = 0.1f;
+                p.pro_slope = (opr && !r16) ? 1.f : 0.1f;          // operand-ready inputs are already activated
                 p.algo_macs = (double)Bc * Lc * c * (double)cout * k;          // Cin*Cout*k*Lin
                 if ((rc = si_launch_tapgemm(ctx, Ly.ups[i].math, p, st))) return rc;
             }
-            if ((rc = si_tap(ctx, upn[i], U, (long)Bc * Lo * cout, st))) return rc;
+            if (!r16 && (rc = si_tap(ctx, upn[i], U, (long)Bc * Lo * cout, st))) return rc;
             // B3: multi-receptive-field fusion: mean over the resblocks, accumulated into xs by the last conv of each
             for (int j = 0; j < nk; ++j) {
                 const ResW& R = Ly.rbs[(size_t)i * nk + j];
@@ -909,9 +918,9 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                     TapGemmParams p = gemm_params(ctx, R.c1[n]);
                     p.x = y; p.out = t;
                     if (opr) { p.x = nullptr; p.x16 = y16; p.out = nullptr; p.out16 = t16; p.out16_slope = 0.1f; }
+                    p.pro_slope = (opr && !r16) ? 1.f : 0.1f;
                     p.nseg = Bc; p.Lin = (int)Lo; p.M = (int)Lo; p.ldx = cout; p.x_seg_stride = Lo * cout;
                     p.dil = dl; p.pad = dl * (rk - 1) / 2; p.ldo = cout; p.o_seg_stride = Lo * cout; p.olimit = p.o_seg_stride;
-                    p.pro_slope = 0.1f;
                     if ((rc = si_launch_tapgemm(ctx, R.c1[n].math, p, st))) return rc;
                     const bool last = (n == d.num_dil - 1);
                     float* ynext = last ? xs : buf[4 + (n & 1)];
@@ -920,27 +929,29 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                     q.x = t; q.out = ynext; q.res = y;
                     if (opr) {
                         q.x = nullptr; q.x16 = t16;
+                        if (r16) { q.res = nullptr; q.res16 = y16; q.out = nullptr; }
                         // the 16-bit copy is wanted by the next c1 of this block, or -- once the MRF mean is complete --
                         // by the next stage's upsampler; conv_post reads fp32
-                        const bool want16 = !last || (j == nk - 1 && i + 1 < d.num_ups);
-                        if (want16) { q.out16 = ynext16; q.out16_slope = 0.1f; }
+                        const bool want16 = r16 || !last || (j == nk - 1 && i + 1 < d.num_ups);
+                        if (want16) { q.out16 = ynext16; q.out16_slope = r16 ? 1.f : 0.1f; }
                     }
                     q.nseg = Bc; q.Lin = (int)Lo; q.M = (int)Lo; q.ldx = cout; q.x_seg_stride = Lo * cout;
                     q.dil = 1; q.pad = (rk - 1) / 2; q.ldo = cout; q.o_seg_stride = Lo * cout; q.olimit = q.o_seg_stride;
-                    q.pro_slope = 0.1f;
-                    if (last) { q.alpha = 1.0f / nk; q.accumulate = (j > 0); }
+                    q.pro_slope = opr ? 1.f : 0.1f;               // the intermediate is stored activated in the 16-bit modes
+                    if (last) { q.alpha = 1.0f / nk; q.accumulate = (j > 0); q.acc16 = (r16 && j > 0); }
                     if ((rc = si_launch_tapgemm(ctx, R.c2[n].math, q, st))) return rc;
                     y = ynext;
                     y16 = ynext16;
                 }
             }
-            if ((rc = si_tap(ctx, stn[i], xs, (long)Bc * Lo * cout, st))) return rc;
+            if (!r16 && (rc = si_tap(ctx, stn[i], xs, (long)Bc * Lo * cout, st))) return rc;
             std::swap(x, xs);
             std::swap(x16, xs16);
             Lc = Lo; c = cout;
         }
         // B4: leaky_relu(0.01) -> conv_post -> tanh
-        return si_launch_conv_post(ctx, x, wf(ctx, Ly.post_w), wf(ctx, Ly.post_b), Bc, (int)Lc, c, 7, wav_out + (size_t)b0 * Lwav, st);
+        return si_launch_conv_post(ctx, x, wf(ctx, Ly.post_w), wf(ctx, Ly.post_b), Bc, (int)Lc, c, 7, wav_out + (size_t)b0 * Lwav, st,
+                                   r16 ? x16 : nullptr);
     };
 
     for (int b0 = 0; b0 < B; b0 += Bc_max) {

@@ -29,11 +29,13 @@ enum { SI_ACT_NONE = 0, SI_ACT_GELU = 1 };
 
 struct TapGemmParams {
     const float* x;        // [nseg][Lin][ldx] fp32, channels-last (NULL when x16 is given)
-    const unsigned short* x16;  // same geometry, operand-ready: already activated and rounded to the math mode's 16-bit type
+    const unsigned short* x16;  // same geometry, 16-bit in the math mode's operand type; pro_slope (if != 1) is applied to it while staging
     const void* w;         // [groups][ntaps][Npad][Cin]  (fp32, or bf16 hi plane)
     const void* w_lo;      // bf16x3: lo plane, same layout
     const float* bias;     // [groups*N] or nullptr
     const float* res;      // residual, indexed like out, or nullptr
+    const unsigned short* res16;  // residual as raw 16-bit values of the math mode's type (instead of res)
+    int acc16;             // accumulate reads the previous value from out16 (raw 16-bit) instead of out
     float* out;            // fp32 output (may be NULL when only out16 is wanted)
     unsigned short* out16; // optional operand-ready copy for the consumer: type16(leaky_relu(v, out16_slope)), indexed like out
     float out16_slope;     // the consumer's prologue slope (1 = identity)
@@ -135,4 +137,4 @@ int si_launch_extend_mel(si_ctx* ctx, const float* mel, int B, int D, int Tm, in
                          hipStream_t st);
 // leaky_relu(0.01) -> Conv1d(C -> 1, k, pad k/2) -> tanh ; x (B, L, C) channels-last -> wav (B, L)
 int si_launch_conv_post(si_ctx* ctx, const float* x, const float* w /*[k][C]*/, const float* bias, int B, int L, int C, int k,
-                        float* wav, hipStream_t st);
+                        float* wav, hipStream_t st, const unsigned short* x16 = nullptr /* raw fp16 input instead of x */);

@@ -193,7 +193,22 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
             const int r = a_r0 + i * (NT / V4), j = a_j;
             if (r < rowsA) {
                 if constexpr (A16) {
-                    *reinterpret_cast<f32x2*>(dst + r * LD + 4 * j) = ra[LO + i];
+                    f32x2 raw = ra[LO + i];
+                    if (slope != 1.f) {          // raw 16-bit activation stream: the prologue activation on packed values
+                        if constexpr (MATH == SI_MATH_F16) {
+                            f16x4 h = __builtin_bit_cast(f16x4, raw);
+                            const f16x4 hs = h * (_Float16)slope;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) h[e] = h[e] > (_Float16)0 ? h[e] : hs[e];
+                            raw = __builtin_bit_cast(f32x2, h);
+                        } else {
+                            f32x4 f = __builtin_convertvector(__builtin_bit_cast(bf16x4, raw), f32x4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) f[e] = f[e] > 0.f ? f[e] : f[e] * slope;
+                            raw = __builtin_bit_cast(f32x2, __builtin_convertvector(f, bf16x4));
+                        }
+                    }
+                    *reinterpret_cast<f32x2*>(dst + r * LD + 4 * j) = raw;
                     continue;
                 }
                 f32x4 v;
@@ -443,8 +458,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
     // p.out may be NULL when only the operand-ready 16-bit copy is wanted (p.out16); the descriptor then has 0 records
     float* const outp = p.out ? p.out + (long)seg * p.o_seg_stride : nullptr;
     const float* const resp = p.res ? p.res + (long)seg * p.o_seg_stride : outp;
-    const bool has_res = p.res != nullptr;
+    const bool has_res = p.res != nullptr || p.res16 != nullptr;
+    const bool res_is16 = p.res16 != nullptr;
     const bool acc_out = p.accumulate != 0;
+    const bool acc_is16 = p.acc16 != 0;
     const bool has_out = p.out != nullptr;
     const bool has_o16 = p.out16 != nullptr;
     const float slope16 = p.out16_slope;
@@ -454,6 +471,17 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(resp), 0, resp ? nbytes : 0, 0x00020000);
     unsigned short* const o16p = has_o16 ? p.out16 + (long)seg * p.o_seg_stride : nullptr;
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(o16p, 0, has_o16 ? nbytes / 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r16rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(res_is16 ? p.res16 + (long)seg * p.o_seg_stride : nullptr), 0, res_is16 ? nbytes / 2 : 0, 0x00020000);
+    auto from16 = [](unsigned short h) -> float {
+        if constexpr (MATH == SI_MATH_F16) return (float)__builtin_bit_cast(_Float16, h);
+        else return __builtin_bit_cast(float, (unsigned)h << 16);
+    };
+    // four packed 16-bit values of the math mode's operand type -> fp32
+    auto from16x4 = [](u32x2 pk) -> f32x4 {
+        if constexpr (MATH == SI_MATH_F16) return __builtin_convertvector(__builtin_bit_cast(f16x4, pk), f32x4);
+        else return __builtin_convertvector(__builtin_bit_cast(bf16x4, pk), f32x4);
+    };
     const int rstep = p.ldo * 4;                                   // bytes between output rows
     int vb[TM][TN];
     float bv[TN];
@@ -494,8 +522,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
                         for (int u = 0; u < 2; ++u) {
                             const int off = nok ? obase + (q0 + u) * 8 * rstep : (int)0x80000000;
                             a[u] = *reinterpret_cast<const f32x4*>(tl + (lr + 8 * (q0 + u)) * 36 + lc);
-                            if (has_res) rr[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0));
-                            if (acc_out) oo[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, off, 0, 0));
+                            const int off16 = nok ? off / 2 : (int)0x80000000;
+                            if (has_res) rr[u] = res_is16 ? from16x4(__builtin_amdgcn_raw_buffer_load_b64(r16rsrc, off16, 0, 0))
+                                                          : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0));
+                            if (acc_out) oo[u] = acc_is16 ? from16x4(__builtin_amdgcn_raw_buffer_load_b64(hrsrc, off16, 0, 0))
+                                                          : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, off, 0, 0));
                         }
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
@@ -541,8 +572,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
 #pragma unroll
                 for (int j = 0; j < JG; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        rv[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, vb[i0 + i][j0 + j] + ((r & 3) + 8 * (r >> 2)) * rstep, 0, 0));
+                    for (int r = 0; r < 16; ++r) {
+                        const int off = vb[i0 + i][j0 + j] + ((r & 3) + 8 * (r >> 2)) * rstep;
+                        if (res_is16) rv[i][j][r] = from16(__builtin_amdgcn_raw_buffer_load_b16(r16rsrc, vb[i0 + i][j0 + j] == (int)0x80000000 ? (int)0x80000000 : off / 2, 0, 0));
+                        else rv[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, off, 0, 0));
+                    }
         }
         if (acc_out) {
 #pragma unroll
@@ -550,8 +584,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
 #pragma unroll
                 for (int j = 0; j < JG; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        ov[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(orsrc, vb[i0 + i][j0 + j] + ((r & 3) + 8 * (r >> 2)) * rstep, 0, 0));
+                    for (int r = 0; r < 16; ++r) {
+                        const int off = vb[i0 + i][j0 + j] + ((r & 3) + 8 * (r >> 2)) * rstep;
+                        if (acc_is16) ov[i][j][r] = from16(__builtin_amdgcn_raw_buffer_load_b16(hrsrc, vb[i0 + i][j0 + j] == (int)0x80000000 ? (int)0x80000000 : off / 2, 0, 0));
+                        else ov[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(orsrc, off, 0, 0));
+                    }
         }
 #pragma unroll
         for (int ii = 0; ii < IG; ++ii)
@@ -640,7 +677,7 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     const double macs = p.algo_macs > 0 ? p.algo_macs : (double)p.nseg * p.M * p.N * p.groups * (double)p.Cin * p.ntaps;
     // algorithmic HBM bytes: input once, every output copy once, residual / accumulate reads, weights once
     const double outs = (double)p.M * p.N * p.groups;
-    double bytes = p.nseg * ((a16 ? 2.0 : 4.0) * p.Lin * p.Cin * p.groups + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0) + (p.accumulate ? 4 : 0))) +
+    double bytes = p.nseg * ((a16 ? 2.0 : 4.0) * p.Lin * p.Cin * p.groups + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0) + (p.res16 ? 2 : 0) + (p.accumulate ? (p.acc16 ? 2 : 4) : 0))) +
                    (double)p.groups * p.ntaps * p.N * p.Cin * (MATH == SI_MATH_F32 || MATH == SI_MATH_BF16X3 ? 4 : 2);
     // SI_TG_XCD=1 enables the XCD-aware tile order.  Measured: no gain on any family (encoder GEMMs 4.03 vs 4.08 ms/step,
     // narrow vocoder stages 3.21 vs 3.11): the re-fetched rows come out of the 256 MB Infinity Cache, not HBM.  Off.
@@ -648,6 +685,8 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     TapGemmParams pk = p;
     pk.xcd_remap = xcd_env && grid.x >= 16;
     pk.wide_epilogue = wide;
+    if ((p.res16 || p.acc16) && MATH != SI_MATH_BF16 && MATH != SI_MATH_F16)
+        return si_fail(ctx, SI_EINVAL, "tapgemm: 16-bit residual / accumulate exist in the bf16 and fp16 math modes only");
     si_prof_begin(ctx, name, 2.0 * macs, bytes, st);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, pk);
     si_prof_end(ctx, st);
@@ -723,7 +762,8 @@ int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t
     if (p.M <= 0 || p.nseg <= 0) return SI_OK;
     if (!p.x == !p.x16) return si_fail(ctx, SI_EINVAL, "tapgemm: exactly one of x (fp32) and x16 (operand-ready) must be given");
     if (!p.out && !p.out16) return si_fail(ctx, SI_EINVAL, "tapgemm: no output");
-    if (p.accumulate && !p.out) return si_fail(ctx, SI_EINVAL, "tapgemm: accumulate needs the fp32 output");
+    if (p.accumulate && !(p.acc16 ? (void*)p.out16 : (void*)p.out)) return si_fail(ctx, SI_EINVAL, "tapgemm: accumulate needs its output buffer");
+    if (p.res && p.res16) return si_fail(ctx, SI_EINVAL, "tapgemm: give res or res16, not both");
     if (p.out16 && math != SI_MATH_BF16 && math != SI_MATH_F16)
         return si_fail(ctx, SI_EINVAL, "tapgemm: the 16-bit output copy exists in the bf16 and fp16 math modes only");
     // The epilogue masks through a buffer descriptor of olimit*4 bytes: byte offsets of every tile row (valid or not)

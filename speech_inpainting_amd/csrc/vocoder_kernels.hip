@@ -7,6 +7,7 @@
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void extend_mel_kernel(const float* __restrict__ mel, int D, int Tm, int Tout, int stretch,
                                                          float rscale, float* __restrict__ out, int ldo) {
@@ -49,9 +50,10 @@ int si_launch_extend_mel(si_ctx* ctx, const float* mel, int B, int D, int Tm, in
 
 // 256 output samples per workgroup; the (256 + k - 1) x C input rows are staged (with the leaky-relu applied)
 // into LDS with an odd row stride so the per-lane row walks are bank-conflict free.
-__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, int L, int C, int k,
-                                                        float* __restrict__ wav) {
+// x16 (optional): the input as raw fp16 (the vocoder's fp16 activation stream) instead of fp32 x
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const unsigned short* __restrict__ x16,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, int L, int C,
+                                                        int k, float* __restrict__ wav) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem);              // [(256 + k - 1)][C + 1]
     float* ws = xs + (256 + k - 1) * (C + 1);                // [k][C]
@@ -60,12 +62,15 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     const int pad = k / 2;
     const int rows = 256 + k - 1;
     const int c4n = C / 4;
-    const float* xb = x + (long)b * L * C;
+    const long xoff = (long)b * L * C;
     for (int idx = threadIdx.x; idx < rows * c4n; idx += 256) {
         const int r = idx / c4n, j = idx - r * c4n;
         const int t = t0 - pad + r;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (t >= 0 && t < L) v = *reinterpret_cast<const f32x4*>(xb + (long)t * C + 4 * j);
+        if (t >= 0 && t < L) {
+            if (x16) v = __builtin_convertvector(*reinterpret_cast<const f16x4*>(x16 + xoff + (long)t * C + 4 * j), f32x4);
+            else v = *reinterpret_cast<const f32x4*>(x + xoff + (long)t * C + 4 * j);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) xs[r * (C + 1) + 4 * j + e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
     }
@@ -83,13 +88,13 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
 }
 
 int si_launch_conv_post(si_ctx* ctx, const float* x, const float* w, const float* bias, int B, int L, int C, int k, float* wav,
-                        hipStream_t st) {
+                        hipStream_t st, const unsigned short* x16) {
     if (C % 4 != 0) return si_fail(ctx, SI_EINVAL, "conv_post: C=%d must be a multiple of 4", C);
     if (B <= 0 || L <= 0) return SI_OK;
     const size_t lds = ((size_t)(256 + k - 1) * (C + 1) + (size_t)k * C) * sizeof(float);
     dim3 grid((L + 255) / 256, B);
-    si_prof_begin(ctx, "conv_post", 2.0 * B * L * (double)C * k, 4.0 * B * L * (C + 1.0), st);
-    hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), lds, st, x, w, bias, L, C, k, wav);
+    si_prof_begin(ctx, "conv_post", 2.0 * B * L * (double)C * k, (double)B * L * ((x16 ? 2.0 : 4.0) * C + 4.0), st);
+    hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), lds, st, x, x16, w, bias, L, C, k, wav);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

@@ -11,8 +11,9 @@ weights arrive by one RCCL broadcast, metrics by one all-gather.  Inputs and wei
 region; outputs stay in HBM.
 
 Arithmetic of the headline number: encoder GEMMs on bf16 MFMA (what configs[1] names; attention, head and arg-max in
-fp32); vocoder convolutions on fp16 MFMA with fp32 accumulate ("validated mixed": fp32 operands rounded to fp16 -- an
-11-bit significand, 8x finer than bf16 -- saturating at +-65504; measured waveform RMS error vs the reference 1.1e-4
+fp32); vocoder convolutions on fp16 MFMA with fp32 accumulate and fp16 activation storage ("validated mixed":
+operands and stored activations rounded to fp16 -- an 11-bit significand, 8x finer than bf16 -- saturating at +-65504;
+bias / residual / MRF arithmetic in fp32 on the accumulators; measured waveform RMS error vs the reference 1.35e-4
 against the north-star gate of 1e-3, tests/test_gpu_parity.py).  Two shorter legs on the same inputs are reported in
 the same JSON line: "bf16x3_vocoder" (every fp32 operand split into bf16 hi + lo, three MFMAs per product: 1.5e-6
 RMS, fp32-equivalent) and "fp32_vocoder" (exact fp32 MFMA), and `vocoder_check` holds the live RMS difference between
@@ -253,7 +254,7 @@ def main():
 
     dtype_txt = {"fp32": "fp32 (exact fp32 MFMA)", "bf16": "bf16 MFMA, fp32 accumulate",
                  "bf16x3": "bf16x3 (fp32 operands split hi+lo, 3 bf16 MFMAs per product, fp32 accumulate: fp32-equivalent)",
-                 "fp16": "fp16 MFMA (operands rounded to fp16, saturating), fp32 accumulate"}
+                 "fp16": "fp16 MFMA (operands rounded to fp16, saturating), fp32 accumulate, activations stored as fp16"}
     clips = main_run["clips"]
     res = {
         "metric": "real-time factor (audio-sec/wall-sec), 4 s clips @16 kHz, 200 ms mask",

@@ -12,6 +12,7 @@
  *                           I_ea/loss_fn.py:29-62 ; I_ea/predict.py:171-173
  *   si_kmeans_assign     <- kmeans_model.predict(feats) (row f-2)   I_da/scripts/inpainting.py:204-205 ;
  *                           ApplyKmeans.__call__                    I_ea/dataset/km_label.py:20-24
+ *   si_resample_poly     <- librosa.load(..., sr=22050 / 16000) resampling (row f-3)   I_ea/predict.py:79-80
  *   si_mel_frontend      <- 22.05 kHz masking + normalize*0.95 + get_mel
  *                           I_ea/predict.py:99-106 ; I_ea/dataset/mel_dump.py:40-98
  *   si_hifigan_forward   <- extend_mel + Generator.forward     I_ea/hifi_gan/inference_modified.py:16-19 ;
@@ -152,6 +153,15 @@ int si_codebook_metrics(si_ctx* ctx, const float* feats, int B, int T, const int
  * labels device int64 (rows), sq_dist optional device fp32 (rows).  Needs no weights. */
 int si_kmeans_assign(si_ctx* ctx, const float* feats, int64_t rows, int D, const float* centroids, int K, int64_t* labels,
                      float* sq_dist, si_stream_t stream);
+
+/* Polyphase FIR resampler: the sample-rate conversions in front of the path, `librosa.load(path,
+ * sr=22050)` / `sr=16000` at I_ea/predict.py:79-80.  y = upfirdn(taps, x, up, down)[pre_remove : pre_remove + n_out], i.e.
+ * scipy.signal.resample_poly's arithmetic with a caller-designed filter: taps (device fp32) are the low-pass FIR
+ * multiplied by `up` and already zero-pre-padded as resample_poly pads them; the host helper that designs them is
+ * speech_inpainting_amd/audio.py::design_resampler.  x device fp32 (B, n_in), y device fp32 (B, n_out).  librosa's own
+ * resampler (soxr / resampy) is a different filter; it is absent from the build image, so parity is against scipy. */
+int si_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const float* taps, int ntaps, int up, int down,
+                     int pre_remove, int n_out, float* y, si_stream_t stream);
 
 /* Vocoder: mel (B, D, Tm) -> time-stretch x441/256 -> generator -> wav_out (B, floor(Tm*441/256) * hop).
  * stretch = 0 skips extend_mel (mel already at the generator's frame rate; output (B, Tm * hop)). */

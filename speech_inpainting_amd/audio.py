@@ -33,12 +33,35 @@ def read_wav(path: str):
     return x, int(sr)
 
 
+KAISER_BETA = 14.769656459379492
+
+
+def design_resampler(sr_in: int, sr_out: int, n_in: int):
+    """Filter and index bookkeeping of `scipy.signal.resample_poly(x, up, down, window=("kaiser", beta))` for the GPU
+    resampler (si_resample_poly): returns (taps float32 incl. resample_poly's zero pre-padding, up, down, pre_remove,
+    n_out).  The filter is designed in float64 exactly as resample_poly designs it (firwin(2 * 10 * max(up, down) + 1,
+    1 / max(up, down)) * up) and rounded to float32 once."""
+    from scipy.signal import firwin
+    g = math.gcd(int(sr_in), int(sr_out))
+    up, down = int(sr_out) // g, int(sr_in) // g
+    n_out = n_in * up
+    n_out = n_out // down + bool(n_out % down)
+    half_len = 10 * max(up, down)
+    h = firwin(2 * half_len + 1, 1.0 / max(up, down), window=("kaiser", KAISER_BETA)) * up
+    n_pre_pad = down - half_len % down
+    n_pre_remove = (half_len + n_pre_pad) // down
+    taps = np.concatenate([np.zeros(n_pre_pad), h]).astype(np.float32)
+    return taps, up, down, n_pre_remove, n_out
+
+
 def resample(x: np.ndarray, sr_in: int, sr_out: int) -> np.ndarray:
+    """Host (scipy) resampler with the same filter: the reference of the GPU one in the tests; predict.py resamples on
+    the GPU (InpaintingEngine.resample)."""
     if sr_in == sr_out:
         return x.astype(np.float32)
     from scipy.signal import resample_poly
     g = math.gcd(sr_in, sr_out)
-    return resample_poly(x.astype(np.float64), sr_out // g, sr_in // g, window=("kaiser", 14.769656459379492)).astype(np.float32)
+    return resample_poly(x.astype(np.float64), sr_out // g, sr_in // g, window=("kaiser", KAISER_BETA)).astype(np.float32)
 
 
 def load_audio(path: str, sr: int) -> np.ndarray:

@@ -809,6 +809,14 @@ int si_kmeans_assign(si_ctx* ctx, const float* feats, int64_t rows, int D, const
     return si_launch_kmeans_assign(ctx, feats, (long)rows, D, centroids, K, labels, sq_dist, static_cast<hipStream_t>(stream));
 }
 
+int si_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const float* taps, int ntaps, int up, int down,
+                     int pre_remove, int n_out, float* y, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!x || !taps || !y || B <= 0 || n_in <= 0) return si_fail(ctx, SI_EINVAL, "si_resample_poly: NULL / empty argument");
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    return si_launch_resample_poly(ctx, x, B, n_in, taps, ntaps, up, down, pre_remove, n_out, y, static_cast<hipStream_t>(stream));
+}
+
 int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch, float* wav_out, void* workspace,
                        size_t workspace_bytes, si_stream_t stream) {
     if (!ctx) return SI_EINVAL;

@@ -128,6 +128,10 @@ int si_launch_mel_frames(si_ctx* ctx, const float* wav, const int32_t* ms, const
 int si_launch_mel_project(si_ctx* ctx, const float* spec, int ld_spec, int nbin, const float* basis_t, const int32_t* lo,
                           const int32_t* hi, int nmel, int B, int Tm, float* mel, hipStream_t st);
 
+// polyphase FIR resampler (upfirdn with resample_poly's centring); taps are device fp32, already pre-padded
+int si_launch_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const float* taps, int ntaps, int up, int down,
+                            int pre_remove, int n_out, float* y, hipStream_t st);
+
 // ------------------------------------------------------------------------------------------------
 // vocoder kernels (vocoder_kernels.hip)
 // ------------------------------------------------------------------------------------------------

@@ -115,3 +115,47 @@ int si_launch_mel_project(si_ctx* ctx, const float* spec, int ld_spec, int nbin,
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ f-3: resampler
+// Polyphase FIR resampling y = (x up-sampled by `up`) * h, down-sampled by `down` -- scipy.signal.upfirdn's definition,
+// with resample_poly's centring (the taps arrive already zero-pre-padded; `pre_remove` leading outputs are dropped):
+//     y[m'] = sum_j h[(m' + pre_remove) * down - j * up] * x[j]        over the j that keep the tap index in [0, ntaps)
+// One thread per output sample; the tap table sits in LDS (8.8 k taps for 22.05 kHz -> 16 kHz), a thread walks every
+// `up`-th tap from its phase while its input index walks down -- neighbouring threads read neighbouring inputs.
+__global__ __launch_bounds__(256) void resample_poly_kernel(const float* __restrict__ x, int n_in, const float* __restrict__ taps,
+                                                            int ntaps, int up, int down, int pre_remove, int n_out,
+                                                            float* __restrict__ y) {
+    extern __shared__ float hs[];
+    for (int i = threadIdx.x; i < ntaps; i += 256) hs[i] = taps[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= n_out) return;
+    const long t = (long)(m + pre_remove) * down;
+    long j = t / up;                                  // newest input that can touch this output
+    int k = (int)(t - j * up);                        // its tap
+    if (j > n_in - 1) { const long skip = j - (n_in - 1); k += (int)(skip * up); j = n_in - 1; }
+    const float* xb = x + (long)b * n_in;
+    float acc = 0.f;
+    for (; k < ntaps && j >= 0; k += up, --j) acc = fmaf(hs[k], xb[j], acc);
+    y[(long)b * n_out + m] = acc;
+}
+
+int si_launch_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const float* taps, int ntaps, int up, int down,
+                            int pre_remove, int n_out, float* y, hipStream_t st) {
+    if (up < 1 || down < 1 || ntaps < 1 || (size_t)ntaps * 4 > 150 * 1024)
+        return si_fail(ctx, SI_EINVAL, "resample: up=%d down=%d ntaps=%d (tap table must fit 150 KB of LDS)", up, down, ntaps);
+    if (B <= 0 || n_out <= 0) return SI_OK;
+    auto kern = resample_poly_kernel;
+    const size_t lds = (size_t)ntaps * sizeof(float);
+    static size_t lds_set = 0;
+    if (lds > 64 * 1024 && lds > lds_set) {
+        SI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    si_prof_begin(ctx, "resample_poly", 2.0 * B * n_out * ((double)ntaps / up), 4.0 * B * ((double)n_in + n_out), st);
+    hipLaunchKernelGGL(kern, dim3((n_out + 255) / 256, B), dim3(256), lds, st, x, n_in, taps, ntaps, up, down, pre_remove, n_out, y);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}

@@ -37,6 +37,7 @@ class InpaintingEngine:
         self.device = torch.device(device)
         self.encoder_dtype, self.vocoder_dtype = encoder_dtype, vocoder_dtype
         self.ctx = NativeContext(make_desc(harch, varch, num_clusters, encoder_dtype, vocoder_dtype, vocoder_chunk), self.device)
+        self._resamplers = {}
 
     # ---- weights
     def load_state(self, hubert_sd: Mapping[str, torch.Tensor], gen_sd: Mapping[str, torch.Tensor], codebook: torch.Tensor):
@@ -67,6 +68,19 @@ class InpaintingEngine:
         """Vocoder-side front-end (I_ea/predict.py:99-106): zero [mask_start, mask_end) of each raw 22.05 kHz clip,
         peak-normalise * 0.95, log-mel -> (B, 80, Tm)."""
         return self.ctx.mel_frontend(wave22, mask_start, mask_end, normalize)
+
+    def resample(self, x: torch.Tensor, sr_in: int, sr_out: int) -> torch.Tensor:
+        """(B, n) fp32 clips at sr_in -> (B, ceil(n * sr_out / sr_in)) at sr_out on the GPU (polyphase Kaiser FIR, the
+        arithmetic of scipy.signal.resample_poly; stands in for librosa.load(..., sr=...) at I_ea/predict.py:79-80)."""
+        from . import audio
+        if sr_in == sr_out:
+            return x.clone()
+        key = (int(sr_in), int(sr_out), int(x.shape[1]))
+        if key not in self._resamplers:
+            taps, up, down, pre, n_out = audio.design_resampler(sr_in, sr_out, x.shape[1])
+            self._resamplers[key] = (torch.from_numpy(taps).to(self.device), up, down, pre, n_out)
+        taps, up, down, pre, n_out = self._resamplers[key]
+        return self.ctx.resample_poly(x.contiguous(), taps, up, down, pre, n_out)
 
     def get_mel(self, x: torch.Tensor) -> torch.Tensor:
         """`get_mel(x)` of I_ea/dataset/mel_dump.py:96-98: x (B, n) already normalised -> (B, 80, Tm) log-mel."""

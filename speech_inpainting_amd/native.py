@@ -22,7 +22,7 @@ SI_MAX_CONV, SI_MAX_UPS, SI_MAX_RB, SI_MAX_DIL = 8, 8, 4, 4
 
 EXPORTS = ["si_version", "si_create", "si_destroy", "si_last_error", "si_load_weights", "si_alloc_weights",
            "si_weights_device_ptr", "si_workspace_bytes", "si_hubert_forward", "si_codebook_splice",
-           "si_codebook_metrics", "si_kmeans_assign", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
+           "si_codebook_metrics", "si_kmeans_assign", "si_resample_poly", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
            "si_vocoder_samples", "si_profile_start", "si_profile_filter", "si_profile_stop",
            "si_debug_capture", "si_debug_size"]
 
@@ -123,6 +123,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.si_codebook_splice.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp]
     lib.si_codebook_metrics.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.si_kmeans_assign.argtypes = [vp, vp, C.c_int64, i32, vp, i32, vp, vp, vp]
+    lib.si_resample_poly.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.si_hifigan_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_mel_frames.argtypes = [i32]
     lib.si_mel_workspace_bytes.argtypes = [vp, i32, i32, C.POINTER(sz)]
@@ -275,6 +276,15 @@ class NativeContext:
         self._check(self.lib.si_kmeans_assign(self._h, _ptr(feats), rows, D, _ptr(centroids), centroids.shape[0], _ptr(labels),
                                               _ptr(dist), self._stream()), "si_kmeans_assign")
         return (labels, dist) if with_distance else labels
+
+    def resample_poly(self, x: torch.Tensor, taps: torch.Tensor, up: int, down: int, pre_remove: int, n_out: int) -> torch.Tensor:
+        """x (B, n_in) -> (B, n_out): upfirdn(taps, x, up, down)[pre_remove : pre_remove + n_out] (see audio.design_resampler)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+        assert taps.is_cuda and taps.dtype == torch.float32 and taps.dim() == 1 and taps.is_contiguous()
+        y = torch.empty(x.shape[0], n_out, dtype=torch.float32, device=self.device)
+        self._check(self.lib.si_resample_poly(self._h, _ptr(x), x.shape[0], x.shape[1], _ptr(taps), taps.numel(), int(up), int(down),
+                                              int(pre_remove), int(n_out), _ptr(y), self._stream()), "si_resample_poly")
+        return y
 
     def hifigan_forward(self, mel: torch.Tensor, stretch: bool = True) -> torch.Tensor:
         assert mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous() and mel.dim() == 3

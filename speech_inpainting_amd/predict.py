@@ -11,7 +11,7 @@ It reads the reference's YAML schema, loads the same three artefacts (CustomMode
 
 Differences from the script, all outside the three replaced subsystems: no Whisper `Metrics` object is built (the
 script constructs it and never uses it, I_ea/predict.py:72-73), PNG plots are skipped, and audio loading / resampling
-uses scipy instead of librosa (see audio.py).
+uses a polyphase Kaiser FIR on the GPU (si_resample_poly; scipy's resample_poly arithmetic) instead of librosa.
 """
 from __future__ import annotations
 
@@ -113,8 +113,10 @@ def main(argv=None) -> int:
     wave_name = cfg.wave_path.split("/")[-1].split(".")[0]
     save_dir = os.path.join(cfg.save_pred, wave_name)
     os.makedirs(save_dir, exist_ok=True)
-    wave_22 = audio.load_audio(cfg.wave_path, 22050)
-    wave_16 = audio.load_audio(cfg.wave_path, 16000)
+    raw, sr_file = audio.read_wav(cfg.wave_path)                                   # predict.py:79-80 (librosa.load x 2):
+    raw_dev = torch.from_numpy(raw)[None].to(engine.device)                        # one read, both rates on the GPU
+    wave_22 = engine.resample(raw_dev, sr_file, 22050)[0].cpu().numpy()
+    wave_16 = engine.resample(raw_dev, sr_file, 16000)[0].cpu().numpy()
     audio.write_wav(os.path.join(save_dir, "orig.wav"), wave_16, 16000)
     pos, lm = cfg.mask_pos, cfg.mask_frames
     masked_16 = wave_16.copy()

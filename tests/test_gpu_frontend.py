@@ -115,3 +115,19 @@ def test_kmeans_assignment_matches_sklearn_and_oracle(ctx):
         assert torch.equal(got[clear], ref_sk[clear]) and torch.equal(got[clear], ref_or[clear]), (rows, D, K)
         assert torch.equal(got[clear], d_all.argmin(1)[clear])
         assert torch.allclose(dist.double(), top2[:, 0], rtol=1e-4, atol=1e-3)
+
+
+def test_gpu_resampler_matches_scipy_resample_poly(ctx):
+    """f-3: si_resample_poly vs scipy.signal.resample_poly with the same Kaiser filter (float64 reference), for the two
+    conversions of the predict path (22.05 kHz file -> 16 kHz; 16 kHz file -> 22.05 kHz) and an odd length."""
+    from scipy.signal import resample_poly
+    from speech_inpainting_amd import audio
+    for sr_in, sr_out, n in ((22050, 16000, 66150), (16000, 22050, 48000), (22050, 16000, 12347), (44100, 16000, 30000)):
+        x = _clips(2, n, 23)
+        taps, up, down, pre, n_out = audio.design_resampler(sr_in, sr_out, n)
+        got = ctx.resample_poly(torch.from_numpy(x).cuda(), torch.from_numpy(taps).cuda(), up, down, pre, n_out).cpu().numpy()
+        ref = resample_poly(x.astype(np.float64), up, down, axis=1, window=("kaiser", audio.KAISER_BETA))
+        assert got.shape == ref.shape == (2, n_out)
+        err = np.abs(got - ref).max()
+        assert err <= 2e-6 * max(1.0, np.abs(ref).max()), (sr_in, sr_out, n, err)
+        assert np.allclose(audio.resample(x[0], sr_in, sr_out), got[0], atol=3e-6)          # the host helper agrees too

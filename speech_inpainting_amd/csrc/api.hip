@@ -867,6 +867,8 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
     // (gate 1e-3).  SI_VOC_RES16=0 keeps the fp32 residual stream.
     static const int res16_env = getenv("SI_VOC_RES16") ? atoi(getenv("SI_VOC_RES16")) : 1;
     const bool r16 = opr && res16_env && d.vocoder_math == SI_MATH_F16;
+    static const int fuse_env = getenv("SI_VOC_FUSE") ? atoi(getenv("SI_VOC_FUSE")) : 1;
+    const bool fuse_pairs = fuse_env != 0;
     if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: vocoder workspace carve exceeded its own estimate");
     if (nstr == 2 && !ctx->aux_stream) {
         SI_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
@@ -922,6 +924,16 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                 const unsigned short* y16 = U16;
                 for (int n = 0; n < d.num_dil; ++n) {
                     const int dl = d.rb_dilations[j][n];
+                    const bool last_n = (n == d.num_dil - 1);
+                    if (r16 && fuse_pairs) {
+                        // narrow stages: conv pair as one kernel, the intermediate stays in LDS (respair.hip)
+                        const TapGemmParams w1 = gemm_params(ctx, R.c1[n]), w2 = gemm_params(ctx, R.c2[n]);
+                        unsigned short* yn16 = last_n ? xs16 : h16[4 + (n & 1)];
+                        const int frc = si_launch_respair(ctx, cout, y16, yn16, w1.w, w2.w, w1.bias, w2.bias, Bc, (int)Lo, rk, dl,
+                                                          last_n ? 1.0f / nk : 1.0f, last_n && j > 0, st);
+                        if (frc < 0) return frc;
+                        if (frc == 0) { y16 = yn16; continue; }
+                    }
                     float* t = buf[3];
                     TapGemmParams p = gemm_params(ctx, R.c1[n]);
                     p.x = y; p.out = t;

@@ -132,6 +132,11 @@ int si_launch_mel_project(si_ctx* ctx, const float* spec, int ld_spec, int nbin,
 int si_launch_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const float* taps, int ntaps, int up, int down,
                             int pre_remove, int n_out, float* y, hipStream_t st);
 
+// One ResBlock1 step y' = (y + conv2(lrelu(conv1(lrelu(y)) + b1)) + b2) * alpha [+ previous y'] as one kernel on the raw
+// fp16 activation stream (respair.hip; C = 32 / 64).  Returns 1 when the shape is not covered.
+int si_launch_respair(si_ctx* ctx, int C, const unsigned short* y16, unsigned short* out16, const void* w1, const void* w2,
+                      const float* b1, const float* b2, int B, int L, int k, int dil, float alpha, int accumulate, hipStream_t st);
+
 // ------------------------------------------------------------------------------------------------
 // vocoder kernels (vocoder_kernels.hip)
 // ------------------------------------------------------------------------------------------------

@@ -34,6 +34,7 @@ print("RESULT " + json.dumps(out))
 
 COMBOS = [
     {"SI_VOC_RES16": "0"},                                   # fp16 operands, fp32 residual stream
+    {"SI_VOC_FUSE": "0"},                                    # fp16 stream with the conv pairs as two launches
     {"SI_VOC_OPREADY": "0", "SI_ENC_OPREADY": "0"},         # consumers convert fp32 activations while staging
     {"SI_TG_WIDE_EPI": "0"},                                 # per-lane scalar epilogue in the light kernels
     {"SI_TG_PP": "1", "SI_TG_XCD": "1"},                     # ping-pong kernel variant + XCD-aware tile order

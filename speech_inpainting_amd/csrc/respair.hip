@@ -8,6 +8,8 @@
 //   phase 1   t[R1 rows] = lrelu(conv1(lrelu(y)) + b1)      rows [m0 - p2, m0 - p2 + R1), zero outside the clip
 //                                                           (conv2's zero padding applies to t), fp16 into LDS
 //   phase 2   out[BMo rows] = (conv2(t) + b2 + y) * alpha (+ previous out)      BMo = R1 - (k - 1)
+// The intermediate tile is written OVER the activation tile (dead once conv1 is done): 29.5 KB (C = 32) / 62 KB (C = 64)
+// of LDS per workgroup, i.e. five / two resident workgroups per CU.
 // conv1 is recomputed on the k - 1 halo rows between neighbouring tiles (1-8 %).  Weight slabs (C x C per tap) stream
 // through a double buffer for both convolutions; activations arrive as raw fp16 (leaky-ReLU applied while staging), the
 // residual is re-read from global (L2-hot) in the epilogue, which is row-contiguous (8-byte accesses after an LDS
@@ -40,7 +42,7 @@ struct ResPairParams {
 
 template <int C>
 __global__ __launch_bounds__(256, 3) void respair_kernel(const ResPairParams p) {
-    constexpr int R1 = C == 32 ? 256 : 128;              // intermediate rows per workgroup
+    constexpr int R1 = 256;                              // intermediate rows per workgroup
     constexpr int TM = R1 / 128;                         // 32-row tiles per wave (4 waves)
     constexpr int TN = C / 32;
     constexpr int LD = C + 8;                            // LDS row stride in halves (16-byte pad)
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256, 3) void respair_kernel(const ResPairParams p) 
     constexpr int V8 = C / 8;                            // 16-byte vectors per weight row
     constexpr int WSLOTS = (C * V8 + 255) / 256;         // 16-byte weight vectors per thread and slab
     constexpr int V4 = C / 4;                            // 8-byte (4-half) slots per activation row
-    constexpr int ASLOTS = C == 32 ? 10 : 12;            // (R1 + 50) * V4 / 256 rounded up
+    constexpr int ASLOTS = C == 32 ? 10 : 20;            // (R1 + 50) * V4 / 256 rounded up
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -63,8 +65,9 @@ __global__ __launch_bounds__(256, 3) void respair_kernel(const ResPairParams p) 
     const int y_row0 = t_row0 - p1;                      // global row of staged activation row 0
 
     unsigned short* Ys = reinterpret_cast<unsigned short*>(smem);          // [R0][LD]   lrelu(y), fp16
-    unsigned short* Ts = Ys + (size_t)(R1 + 50) * LD;                      // [R1][LD]   lrelu(conv1 + b1), fp16
-    unsigned short* Ws = Ts + (size_t)R1 * LD;                             // [2][C][LD] weight slab double buffer
+    unsigned short* Ts = Ys;                                               // [R1][LD]   lrelu(conv1 + b1), fp16: OVER the activation
+                                                                           // tile, which is dead once conv1 is done (one extra barrier)
+    unsigned short* Ws = Ys + (size_t)(R1 + 50) * LD;                      // [2][C][LD] weight slab double buffer
 
     const long seg = (long)b * p.L * C;
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + seg), 0, p.L * C * 2, 0x00020000);
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(256, 3) void respair_kernel(const ResPairParams p) 
             compute(Ts, s - k, Wc);                      // conv2 tap: output row o reads intermediate row o + tap
         }
         if (s == k - 1) {
+            __syncthreads();                             // every wave has finished reading the activation tile
             // ---- phase-1 epilogue: bias, leaky-ReLU, zero outside the clip, fp16, into the intermediate tile
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -213,10 +217,10 @@ __global__ __launch_bounds__(256, 3) void respair_kernel(const ResPairParams p) 
 
 template <int C>
 static int respair_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t st) {
-    constexpr int R1 = C == 32 ? 256 : 128;
+    constexpr int R1 = 256;
     constexpr int LD = C + 8;
     const int BMo = R1 - (p.k - 1);
-    size_t lds = ((size_t)(R1 + 50) * LD + (size_t)R1 * LD + 2 * (size_t)C * LD) * 2;
+    size_t lds = ((size_t)(R1 + 50) * LD + 2 * (size_t)C * LD) * 2;
     lds = std::max(lds, (size_t)4 * 32 * 36 * sizeof(float));
     auto kern = respair_kernel<C>;
     static size_t lds_set = 0;

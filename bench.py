@@ -10,8 +10,8 @@ encoder GEMMs on bf16 MFMA with fp32 accumulate); at N > 1 utterances are sharde
 weights arrive by one RCCL broadcast, metrics by one all-gather.  Inputs and weights are in HBM before the timed
 region; outputs stay in HBM.
 
-Arithmetic of the headline number: encoder GEMMs on bf16 MFMA (what configs[1] names; attention, head and arg-max in
-fp32); vocoder convolutions on fp16 MFMA with fp32 accumulate and fp16 activation storage ("validated mixed":
+Arithmetic of the headline number: encoder GEMMs and attention products on bf16 MFMA (what configs[1] names; softmax,
+LayerNorm, head and arg-max in fp32); vocoder convolutions on fp16 MFMA with fp32 accumulate and fp16 activation storage ("validated mixed":
 operands and stored activations rounded to fp16 -- an 11-bit significand, 8x finer than bf16 -- saturating at +-65504;
 bias / residual / MRF arithmetic in fp32 on the accumulators; measured waveform RMS error vs the reference 1.35e-4
 against the north-star gate of 1e-3, tests/test_gpu_parity.py).  Two shorter legs on the same inputs are reported in
@@ -262,7 +262,7 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * main_run["elapsed"] / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": f"encoder GEMMs: {dtype_txt[a.encoder_dtype]} (attention, head, arg-max in fp32); vocoder: {dtype_txt[a.vocoder_dtype]}",
+        "dtype": f"encoder GEMMs and attention products: {dtype_txt[a.encoder_dtype]} (softmax, LayerNorm, head, arg-max in fp32); vocoder: {dtype_txt[a.vocoder_dtype]}",
         "data": "synthetic (seeded clips, random-init weights of the HuBERT-base + HiFi-GAN V1 architecture)",
         "config": {"workload": "BASELINE configs[1]: batch=32 x 4 s clips per GPU, 200 ms mask, HuBERT-base + HiFi-GAN V1; step = masked log-mel front-end -> encoder -> arg-max/splice -> vocoder on resident raw clips"
                                + ("" if world == 1 else f", utterance-sharded over {world} GPUs (configs[2] at 8)"),

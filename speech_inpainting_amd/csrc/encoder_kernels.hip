@@ -15,6 +15,8 @@
 //    round trip, no shuffles; cdna_hip_programming.md section 3 "An accumulator tile as the next MFMA's operand").
 //  * codebook_splice : cosine arg-max against centred centroids + raw-centroid splice (I_ea/loss_fn.py:44-47,
 //    I_ea/predict.py:164-168,184-187).
+#include <cstdlib>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -449,13 +451,135 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
+// bf16 MFMA form for the bf16 encoder mode: same tiling and online softmax (fp32), but S^T = K Q^T and O^T = V^T P^T on
+// v_mfma_f32_32x32x16_bf16 (4 + 4 instructions per 32-key tile instead of 32 + 32 fp32 ones).  K is staged as bf16
+// [key][d]; V is staged TRANSPOSED as bf16 [d][key], because the P^T operand comes straight out of the score
+// accumulators: k-slot i of lane-half h of MFMA step st is score register 8*st + i, i.e. key 16*st + 4*h + (i & 3) +
+// 8*(i >> 2) -- two runs of four consecutive keys, which the V^T operand reads as two 8-byte LDS loads of row d.
+#define ATB_LDK 72    // 64 + 8 halves: 144-byte rows
+#define ATB_LDV 40    // 32 + 8 halves: 80-byte rows
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __restrict__ qkv, unsigned short* __restrict__ out16, int T,
+                                                             int H, int heads) {
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[ATT_KT * ATB_LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Vt[64 * ATB_LDV];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const long ld = 3L * H;
+    const float* base = qkv + (long)b * T * ld + h * 64;
+
+    bf16x8 qb[4];                                          // query row, 8 dims per k-step and lane half, scaled by 2^-3
+    {
+        const int qrow = min(q0 + l31, T - 1);
+        const float* qp = base + (long)qrow * ld;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 8 * half);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 8 * half + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qb[ks][e] = (__bf16)(t0[e] * 0.125f); qb[ks][4 + e] = (__bf16)(t1[e] * 0.125f); }
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float mrun = -INFINITY, lrun = 0.f;
+
+    for (int k0 = 0; k0 < T; k0 += ATT_KT) {
+        __syncthreads();
+        for (int idx = tid; idx < ATT_KT * 16; idx += 256) {
+            const int r = idx >> 4, j = idx & 15;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + r < T) kv = *reinterpret_cast<const f32x4*>(base + (long)(k0 + r) * ld + H + 4 * j);
+            *reinterpret_cast<bf16x4*>(Ks + r * ATB_LDK + 4 * j) = __builtin_convertvector(kv, bf16x4);
+        }
+        // V transposed: a thread takes two consecutive keys x four dims and writes four packed 32-bit words
+        {
+            const int rp = tid >> 4, j = tid & 15;                  // key pair 0..15, dim group 0..15
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + 2 * rp < T) v0 = *reinterpret_cast<const f32x4*>(base + (long)(k0 + 2 * rp) * ld + 2 * H + 4 * j);
+            if (k0 + 2 * rp + 1 < T) v1 = *reinterpret_cast<const f32x4*>(base + (long)(k0 + 2 * rp + 1) * ld + 2 * H + 4 * j);
+            // (whole-vector bit casts: extracting single __bf16 lanes with __builtin_bit_cast returned lane 0 for every index)
+            typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x2_t w0 = __builtin_bit_cast(u32x2_t, __builtin_convertvector(v0, bf16x4));
+            const u32x2_t w1 = __builtin_bit_cast(u32x2_t, __builtin_convertvector(v1, bf16x4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned lo = (w0[e >> 1] >> (16 * (e & 1))) & 0xffffu, hi = (w1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                *reinterpret_cast<unsigned*>(Vt + (4 * j + e) * ATB_LDV + 2 * rp) = lo | (hi << 16);
+            }
+        }
+        __syncthreads();
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + l31 * ATB_LDK + 16 * ks + 8 * half);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qb[ks], s, 0, 0, 0);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (key >= T) s[r] = -INFINITY;
+            tmax = fmaxf(tmax, s[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mrun, tmax);
+        const float alpha = __expf(mrun - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - mnew); psum += s[r]; }
+        psum += __shfl_xor(psum, 32, 64);
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 pb;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pb[i] = (__bf16)s[8 * st + i];
+            const unsigned short* v0p = Vt + l31 * ATB_LDV + 16 * st + 4 * half;
+            const unsigned short* v1p = Vt + (32 + l31) * ATB_LDV + 16 * st + 4 * half;
+            bf16x8 va, vc;
+            const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(v0p), a1 = *reinterpret_cast<const bf16x4*>(v0p + 8);
+            const bf16x4 c0 = *reinterpret_cast<const bf16x4*>(v1p), c1 = *reinterpret_cast<const bf16x4*>(v1p + 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { va[e] = a0[e]; va[4 + e] = a1[e]; vc[e] = c0[e]; vc[4 + e] = c1[e]; }
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc, pb, o1, 0, 0, 0);
+        }
+    }
+    const int q = q0 + l31;
+    if (q < T) {
+        const float inv = 1.0f / lrun;
+        const long o = ((long)b * T + q) * H + h * 64;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = 8 * g4 + 4 * half;
+            f32x4 a = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
+            f32x4 c = {o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv};
+            *reinterpret_cast<bf16x4*>(out16 + o + d) = __builtin_convertvector(a, bf16x4);
+            *reinterpret_cast<bf16x4*>(out16 + o + 32 + d) = __builtin_convertvector(c, bf16x4);
+        }
+    }
+}
+
 int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st,
                         unsigned short* out16) {
     if (heads <= 0 || H != heads * 64) return si_fail(ctx, SI_EINVAL, "attention kernel needs head_dim 64 (H=%d heads=%d)", H, heads);
     if (B <= 0 || T <= 0) return SI_OK;
     dim3 grid((T + 127) / 128, B * heads);
-    si_prof_begin(ctx, "attention_f32", 4.0 * B * (double)T * T * H, 16.0 * B * T * H, st);   // 2*T^2*H MACs (QK^T + PV)
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, qkv, out, out16, T, H, heads);
+    // bf16 encoder mode (out16 given): the bf16-MFMA form; SI_ATT_BF16=0 keeps the exact-fp32 MFMA kernel there too
+    static const int att_bf16 = getenv("SI_ATT_BF16") ? atoi(getenv("SI_ATT_BF16")) : 1;
+    si_prof_begin(ctx, (out16 && att_bf16) ? "attention_bf16" : "attention_f32", 4.0 * B * (double)T * T * H, 16.0 * B * T * H, st);   // 2*T^2*H MACs
+    if (out16 && att_bf16) hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, st, qkv, out16, T, H, heads);
+    else hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, qkv, out, out16, T, H, heads);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

@@ -6,23 +6,22 @@
 // (split into its `stride` output phases: 2 taps with dil = -1, N = stride*Cout, see api.hip).
 // Replaces the torch.nn calls of SURVEY.md 8(a) rows A2-A9, B1-B3.
 //
-// Structure: one 256-thread workgroup (4 waves) owns a BM x BN output tile.  For every K chunk of BK input
+// Structure: one workgroup of 4 or 8 waves owns a BM x BN output tile (the launcher at the bottom picks the shape per
+// layer; DESIGN.md 4.1 has the table and the measurements behind each choice).  For every K chunk of BK input
 // channels the halo'd activation tile ((BM-1)*stride + (ntaps-1)*|dil| + 1 rows) is staged ONCE into LDS and
 // reused by all taps -- a tap is just a row offset into that tile -- while the per-tap BK x BN weight slab
-// (L2-resident, shared by every workgroup) is re-staged per tap.  The prologue activation (leaky-relu) and the
-// fp32 -> bf16 / bf16 hi+lo conversion happen while staging, the epilogue (bias, GELU, residual, scale,
-// accumulate) on the accumulators.
+// (L2-resident, shared by every workgroup) is re-staged per tap.  Activations come either as fp32 (prologue
+// leaky-relu and the fp32 -> bf16 / fp16 / bf16 hi+lo conversion happen while staging) or "operand-ready" as 16-bit
+// values already in the MFMA operand type (template flag A16: staging is a copy); the epilogue (bias, GELU, residual,
+// scale, accumulate, optional 16-bit copy for the consumer) works on the accumulators.
 //
-// Pipeline: the loop runs over (chunk, tap) iterations.  In the bf16 modes an iteration's MFMA work (24 x 32
-// cycles in bf16x3, 8 x 32 in bf16) is SHORTER than the L2 latency of a weight slab, so a slab fetched one
-// iteration ahead stalls every iteration (measured: 32 % MFMA utilisation = two workgroups per CU each retiring
-// one iteration per memory latency).  Weight slabs are therefore prefetched TWO iterations ahead into two
-// register sets; the next activation chunk is issued at the first tap of the current chunk (ntaps-1 iterations
-// ahead), or two chunks ahead in two half-sets for ntaps == 1 (Linear).  Registers are written to the OTHER LDS
-// weight buffer after the MFMAs: one workgroup barrier per iteration (plus one per chunk boundary for
-// convolutions, whose halo'd activation tile is single-buffered to keep two workgroups per CU).
-// All loads are ordinary register loads, so the compiler's counted s_waitcnt vmcnt(N) leaves exactly the
-// younger batches in flight.
+// Pipeline: the loop runs over (chunk, tap) iterations.  In the 16-bit modes an iteration's MFMA work is SHORTER than
+// the L2 latency of a weight slab, so slabs are prefetched TWO iterations ahead into two register sets; the next
+// activation chunk is issued at the first tap of the current chunk, or two chunks ahead in two half-sets for
+// ntaps == 1 (Linear).  Registers are written to the OTHER LDS weight buffer after the MFMAs: one workgroup barrier
+// per iteration (plus one per chunk boundary for convolutions, whose activation tile is single-buffered).  All
+// operand loads go through buffer descriptors (hardware range check instead of predicates) and are issued
+// unconditionally wherever possible, so the compiler's counted s_waitcnt vmcnt(N) leaves the younger batches in flight.
 //
 // MFMA use (cdna_hip_programming.md section 3):
 //   F32    v_mfma_f32_32x32x2_f32 : lane l supplies A[l&31][k=l>>5], B[k=l>>5][l&31].  The k index is a
@@ -30,6 +29,7 @@
 //          steps then read consecutive floats and one ds_read_b128 feeds four steps.
 //   BF16   v_mfma_f32_32x32x16_bf16: lane supplies 8 consecutive k (16 B) of row l&31, k block l>>5.
 //   BF16X3 same instruction three times (lo*hi + hi*lo + hi*hi) for ~fp32 accuracy at 3/16 of the fp32 cost.
+//   F16    v_mfma_f32_32x32x16_f16, same fragment layout; operands saturate at +-65504.
 // LDS rows are padded by 16 B so the 16 rows a ds_read_b128 lane group touches fall on distinct 4-bank slots.
 #include <algorithm>
 #include <cstdio>

@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--cpu-clips", type=int, default=8, help="clips timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the secondary exact-fp32-vocoder leg")
+    ap.add_argument("--graph-leg", action="store_true", help="also replay the step as one hipGraph (informational)")
     a = ap.parse_args()
 
     from speech_inpainting_amd import parallel, synth
@@ -185,7 +186,7 @@ def main():
     s22 = (pos * 320 * 22050 // 16000).to(torch.int32)                       # I_ea/predict.py:99-100
     e22 = ((pos + MASK_FRAMES) * 320 * 22050 // 16000).to(torch.int32)
 
-    def run_mode(enc, voc, steps, warmup, events):
+    def run_mode(enc, voc, steps, warmup, events, graph_leg=False):
         t_load = time.perf_counter()
         eng = parallel.setup_engine(lambda: InpaintingEngine(harch, varch, K, dev, enc, voc, a.vocoder_chunk), checkpoint, rank)
         torch.cuda.synchronize()
@@ -225,6 +226,31 @@ def main():
         parallel.barrier()
         elapsed = time.perf_counter() - t0
         prof = eng.ctx.profile_stop() if events else []
+        # extra, informational: the same step replayed as ONE hipGraph (no per-launch host work, no HIP events) -- what the
+        # ~230 dependent launches of a step cost in gaps.  Never `value`: the contract's roofline needs events in the timed region.
+        graph_ms = None
+        if graph_leg and world == 1:
+            try:
+                eng.ctx.profile_filter(None)
+                g = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    step()
+                torch.cuda.current_stream().wait_stream(side)
+                with torch.cuda.graph(g):
+                    gout = step()
+                g.replay(); torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    g.replay()
+                torch.cuda.synchronize()
+                graph_ms = 1e3 * (time.perf_counter() - t1) / steps
+                if not torch.equal(gout["labels"], out["labels"]):
+                    graph_ms = None
+                del g
+            except Exception as ex:      # capture is best-effort; the measured legs above do not depend on it
+                log(f"[bench] hipGraph leg skipped: {ex!r}")
         wav = out["wave"]
         finite = bool(torch.isfinite(wav).all())
         stats = parallel.gather_metrics([elapsed, float(hi - lo), float(wav.pow(2).mean().sqrt()), float(finite)],
@@ -234,12 +260,12 @@ def main():
         clips = float(stats[:, 1].sum())
         if not bool(stats[:, 3].min()):
             raise SystemExit("non-finite samples in the output waveform")
-        return dict(elapsed=elapsed_max, clips=clips, rms=float(stats[0, 2]), prof=prof, steps=steps, prof_warm=prof_warm,
+        return dict(elapsed=elapsed_max, clips=clips, rms=float(stats[0, 2]), prof=prof, steps=steps, prof_warm=prof_warm, graph_ms=graph_ms,
                     warm_steps=warm_steps,
                     wave=wav if rank == 0 else None, labels=out["labels"] if rank == 0 else None)
 
     events = not a.no_kernel_events
-    main_run = run_mode(a.encoder_dtype, a.vocoder_dtype, a.steps, a.warmup, events)
+    main_run = run_mode(a.encoder_dtype, a.vocoder_dtype, a.steps, a.warmup, events, graph_leg=a.graph_leg)
     # reference legs on the same inputs: the fp32-equivalent split mode and exact fp32 (fewer steps; reported, not `value`)
     legs = {}
     if not a.no_fp32_leg:
@@ -292,6 +318,11 @@ def main():
         if r["prof"]:
             leg["roofline"], leg["kernel_families"] = table(r, f"{a.encoder_dtype}/{voc}")
         res[f"{voc}_vocoder"] = leg
+    if main_run.get("graph_ms"):
+        res["graph_replay"] = {"ms_per_step": round(main_run["graph_ms"], 3),
+                               "value": round(clips * CLIP_SECONDS / (main_run["graph_ms"] * 1e-3), 2),
+                               "note": "the same step captured once and replayed as one hipGraph: no per-launch host work and no "
+                                       "HIP events; informational, not the headline"}
     if "fp32" in legs:
         # same clips, same encoder arithmetic: the difference is the vocoder's operand rounding alone
         ref, got = legs["fp32"]["wave"], main_run["wave"]

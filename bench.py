@@ -54,12 +54,35 @@ def family_math(name: str) -> str:
     return "f32"
 
 
-def cpu_baseline(batch: int):
-    """The CPU oracle (plain torch fp32 restatement of the reference) on this host's cores; bounded sample."""
+def host_cpu_share():
+    """(logical CPUs of the host, CPUs this process may run on): the smaller of its affinity mask and its cgroup CPU
+    quota -- a 1-GPU box of this pool gives a job 16 of the host's CPUs, and torch threads beyond that share only
+    contend with each other."""
+    total = os.cpu_count() or 1
+    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else total
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    share = min(share, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    share = min(share, max(1, int(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) + 0.5)))
+        except Exception:
+            pass
+    return total, max(share, 1)
+
+
+def cpu_baseline(batch: int, budget_s: float = 45.0):
+    """the CPU oracle (plain torch fp32 restatement of the reference, resident tensors, mel
+    front-end included) on every CPU this process may use, 1 warm-up + min of 5 passes at batch 1 and at batch `batch`
+    (8).  Bounded: the pass count at the larger batch shrinks (never below 2) so the whole leg stays under budget_s."""
     from oracle import ref_cpu as R
     from speech_inpainting_amd import synth
     from speech_inpainting_amd.arch import HubertArch, VocoderArch, mel_frames
-    cores = min(os.cpu_count() or 1, 16)
+    total, cores = host_cpu_share()
     torch.set_num_threads(cores)
     harch, varch = HubertArch.base(), VocoderArch.v1()
     hsd, gsd, cb = synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook()
@@ -70,12 +93,31 @@ def cpu_baseline(batch: int):
     s22 = [p * 320 * 22050 // 16000 for p in pos]
     e22 = [(p + MASK_FRAMES) * 320 * 22050 // 16000 for p in pos]
     assert R.masked_mel(wave22[:1], s22[:1], e22[:1]).shape[2] == Tm
-    R.predict_batch(hsd, harch, gsd, varch, cb, wave[:1], R.masked_mel(wave22[:1], s22[:1], e22[:1]), pos[:1], MASK_FRAMES)  # warm-up
-    t0 = time.perf_counter()
-    R.predict_batch(hsd, harch, gsd, varch, cb, wave, R.masked_mel(wave22, s22, e22), pos, MASK_FRAMES)
-    dt = time.perf_counter() - t0
-    return {"value": round(batch * CLIP_SECONDS / dt, 3), "unit": "x real-time (audio-sec/wall-sec)", "cores": cores, "kind": "port",
-            "sample": f"{batch} of the same 4 s clips, one pass, fp32, torch CPU oracle (oracle/ref_cpu.py), {dt:.2f} s wall"}
+
+    def one_pass(n):
+        t0 = time.perf_counter()
+        R.predict_batch(hsd, harch, gsd, varch, cb, wave[:n], R.masked_mel(wave22[:n], s22[:n], e22[:n]), pos[:n], MASK_FRAMES)
+        return time.perf_counter() - t0
+
+    t_begin = time.perf_counter()
+    one_pass(1)                                              # warm-up
+    t1 = [one_pass(1) for _ in range(5)]
+    tb, reps = [], 0
+    if batch > 1:
+        first = one_pass(batch)                              # warm-up at the larger batch
+        left = budget_s - (time.perf_counter() - t_begin)
+        reps = max(2, min(5, int(left / max(first, 1e-3))))
+        tb = [one_pass(batch) for _ in range(reps)]
+    best1, bestb = min(t1), (min(tb) if tb else None)
+    v1 = CLIP_SECONDS / best1
+    vb = batch * CLIP_SECONDS / bestb if bestb else v1
+    return {"value": round(max(v1, vb), 3), "unit": "x real-time (audio-sec/wall-sec)", "cores": cores, "kind": "port",
+            "host_logical_cpus": total, "threads_used": cores,
+            "batch1": {"value": round(v1, 3), "best_s": round(best1, 3), "passes": 5},
+            f"batch{batch}": {"value": round(vb, 3), "best_s": round(bestb, 3) if bestb else None, "passes": reps},
+            "sample": f"torch CPU oracle (oracle/ref_cpu.py), fp32, resident tensors, 1 warm-up + min of 5 passes at batch 1 "
+                      f"and min of {reps} at batch {batch} of the same 4 s clips; {cores} torch threads = this job's CPU share "
+                      f"of the host's {total} logical CPUs; {time.perf_counter() - t_begin:.1f} s of CPU work in all"}
 
 
 def measured_traffic(family: str):

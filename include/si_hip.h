@@ -136,6 +136,12 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
 int si_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, const int32_t* frame_pos, int Lm,
                        float* mel, int Tm, int64_t* labels, si_stream_t stream);
 
+/* Splice GIVEN codewords: mel[b, :, pos_b + j] = C[labels[b, j]] -- the script's `expected_inpaint` branch, which puts the
+ * ground-truth centroids where si_codebook_splice puts the predicted ones (I_ea/predict.py:177-189: all_embeds_t_c[0, labels]
+ * + center_).  labels device int64 (B, Lm); a label outside [0, K) or a frame outside [0, Tm) leaves that column untouched. */
+int si_codebook_splice_labels(si_ctx* ctx, const int64_t* labels, int B, const int32_t* frame_pos, int Lm, float* mel, int Tm,
+                              si_stream_t stream);
+
 /* Loss half of the same LossFunction call: `loss, pred = cos_sim(values, labels)` and
  * `cos_sim_target_labels(pred, labels)` (I_ea/loss_fn.py:29-62, called at I_ea/predict.py:171-173).  feats / frame_pos / Lm
  * as si_codebook_splice (pass the gathered values with T = Lm and frame_pos = 0 to mirror the call exactly).

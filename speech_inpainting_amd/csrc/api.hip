@@ -76,9 +76,7 @@ struct si_ctx {
     std::vector<hipEvent_t> prof_pool;
     size_t prof_used = 0;
     int prof_open = -1;
-    // second stream of the vocoder (si_hifigan_forward runs two halves of a chunk concurrently)
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::map<const void*, size_t> dyn_lds;   // per kernel: dynamic-LDS limit already raised on this context's device
     // constant tables of the mel front-end (built on first use): DFT matrix [Npad][n_fft] = rows cos | -sin, periodic
     // Hann window, transposed Slaney mel basis with the non-zero bin span of every band
     char* fe_dev = nullptr;
@@ -123,6 +121,15 @@ void si_prof_begin(si_ctx* ctx, const char* name, double flops, double bytes, hi
     (void)hipEventRecord(r.a, st);
     ctx->prof_open = (int)ctx->prof_recs.size();
     ctx->prof_recs.push_back(r);
+}
+int si_ensure_dyn_lds(si_ctx* ctx, const void* kern, size_t bytes) {
+    if (bytes <= 64 * 1024) return SI_OK;
+    size_t& have = ctx->dyn_lds[kern];
+    if (bytes > have) {
+        SI_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
+    return SI_OK;
 }
 void si_prof_end(si_ctx* ctx, hipStream_t st) {
     if (ctx->prof_open < 0) return;
@@ -524,10 +531,8 @@ size_t vocoder_ws_bytes(const si_ctx* ctx, int B, int Tm, int stretch) {
     size_t lc_max = (size_t)Tout * d.up_initial_channel;
     long L = Tout; int c = d.up_initial_channel;
     for (int i = 0; i < d.num_ups; ++i) { L *= d.up_rates[i]; c /= 2; lc_max = std::max(lc_max, (size_t)L * c); }
-    const size_t sub = (size_t)(Bc + 1) / 2;                 // two half-chunks, one per stream
     // 6 fp32 activation buffers + 6 half-size buffers for the operand-ready 16-bit copies (bf16 / fp16 modes)
-    size_t f = 2 * (sub * Tout * ctx->lay.mel_ld + 9 * sub * lc_max);
-    f = std::max(f, (size_t)Bc * Tout * ctx->lay.mel_ld + 9 * (size_t)Bc * lc_max);
+    const size_t f = (size_t)Bc * Tout * ctx->lay.mel_ld + 9 * (size_t)Bc * lc_max;
     return f * 4 + 32 * 256;
 }
 
@@ -586,7 +591,6 @@ void si_destroy(si_ctx* ctx) {
     if (ctx->wdev) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->wdev); }
     if (ctx->fe_dev) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->fe_dev); }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
-    if (ctx->aux_stream) { (void)hipStreamDestroy(ctx->aux_stream); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
     delete ctx;
 }
 
@@ -787,6 +791,18 @@ int si_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, const int3
                                      wf(ctx, L.cb_rnorm), ctx->d.num_clusters, mel, Tm, labels, static_cast<hipStream_t>(stream));
 }
 
+int si_codebook_splice_labels(si_ctx* ctx, const int64_t* labels, int B, const int32_t* frame_pos, int Lm, float* mel, int Tm,
+                              si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!ctx->weights_ready) return si_fail(ctx, SI_ESTATE, "si_codebook_splice_labels before weights were loaded");
+    if (!labels || !frame_pos || !mel || B <= 0 || Lm < 0) return si_fail(ctx, SI_EINVAL, "si_codebook_splice_labels: NULL / empty argument");
+    if (ctx->d.codebook_dim != ctx->d.num_mels)
+        return si_fail(ctx, SI_EINVAL, "codebook_dim %d != generator input width %d", ctx->d.codebook_dim, ctx->d.num_mels);
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    return si_launch_codebook_gather(ctx, labels, B, ctx->d.codebook_dim, frame_pos, Lm, wf(ctx, ctx->lay.cb_raw), ctx->d.num_clusters,
+                                     mel, Tm, static_cast<hipStream_t>(stream));
+}
+
 int si_codebook_metrics(si_ctx* ctx, const float* feats, int B, int T, const int32_t* frame_pos, int Lm,
                         const int64_t* target_labels, float* loss_terms, float* loss, int64_t* pred_labels, float* cos_pred_target,
                         si_stream_t stream) {
@@ -837,23 +853,12 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
         for (int i = 0; i < d.num_ups; ++i) { L *= d.up_rates[i]; c /= 2; lc_max = std::max(lc_max, (size_t)L * c); }
     }
     const long Lwav = si_vocoder_samples(ctx, Tm, stretch);
-    // Opt-in (SI_VOC_STREAMS=2): two independent halves of every chunk on two HIP streams (the caller's and one owned by
-    // the context), so that one half's memory-bound phases (cold prologue, residual reads, store drain: 30-50 % of a
-    // wave's life per the in-kernel stamps) overlap the other half's MFMA phases.  Measured gain at B = 32: 2 % (bf16x3)
-    // to 4 % (fp32) of wall time -- not worth doubling the launch count by default.  Clips are independent, so results
-    // do not change.
-    static const int nstreams_env = getenv("SI_VOC_STREAMS") ? atoi(getenv("SI_VOC_STREAMS")) : 1;
-    const int nstr = (nstreams_env >= 2 && Bc_max >= 2) ? 2 : 1;
-    const int sub_max = (Bc_max + nstr - 1) / nstr;
     Carver W{static_cast<char*>(workspace), workspace_bytes};
-    float* ext_s[2];
-    float* buf_s[2][6];
-    unsigned short* h16_s[2][6];
-    for (int h = 0; h < nstr; ++h) {
-        ext_s[h] = W.floats((size_t)sub_max * Tout * Ly.mel_ld);
-        for (auto& b : buf_s[h]) b = W.floats((size_t)sub_max * lc_max);
-        for (auto& b : h16_s[h]) b = reinterpret_cast<unsigned short*>(W.bytes((size_t)sub_max * lc_max * 2));
-    }
+    float* ext_ws = W.floats((size_t)Bc_max * Tout * Ly.mel_ld);
+    float* buf_ws[6];
+    unsigned short* h16_ws[6];
+    for (auto& b : buf_ws) b = W.floats((size_t)Bc_max * lc_max);
+    for (auto& b : h16_ws) b = reinterpret_cast<unsigned short*>(W.bytes((size_t)Bc_max * lc_max * 2));
     // Operand-ready activations (bf16 / fp16 vocoder): every producer also writes type16(leaky_relu(x, 0.1)) -- exactly
     // what the next convolution would compute while staging -- so consumers copy 2-byte operands instead of loading
     // fp32 and converting; the ResBlock intermediate exists only in that form.  Same arithmetic, bit-identical output;
@@ -870,11 +875,6 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
     static const int fuse_env = getenv("SI_VOC_FUSE") ? atoi(getenv("SI_VOC_FUSE")) : 1;
     const bool fuse_pairs = fuse_env != 0;
     if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: vocoder workspace carve exceeded its own estimate");
-    if (nstr == 2 && !ctx->aux_stream) {
-        SI_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-        SI_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        SI_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    }
     const int nk = d.num_rb;
     static const char* upn[] = {"ups0", "ups1", "ups2", "ups3", "ups4", "ups5", "ups6", "ups7"};
     static const char* stn[] = {"stage0", "stage1", "stage2", "stage3", "stage4", "stage5", "stage6", "stage7"};
@@ -976,18 +976,7 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
 
     for (int b0 = 0; b0 < B; b0 += Bc_max) {
         const int Bc = std::min(Bc_max, B - b0);
-        const int first = nstr == 2 ? (Bc + 1) / 2 : Bc;           // clips of this chunk that stay on the caller's stream
-        int rc;
-        if (first < Bc) {
-            SI_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));        // the second half starts after everything already queued
-            SI_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-        }
-        if ((rc = run(b0, first, ext_s[0], buf_s[0], h16_s[0], st))) return rc;
-        if (first < Bc) {
-            if ((rc = run(b0 + first, Bc - first, ext_s[1], buf_s[1], h16_s[1], ctx->aux_stream))) return rc;
-            SI_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->aux_stream));
-            SI_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
-        }
+        if (int rc = run(b0, Bc, ext_ws, buf_ws, h16_ws, st)) return rc;
     }
     return SI_OK;
 }

@@ -16,6 +16,10 @@ int si_fail(si_ctx* ctx, int code, const char* fmt, ...);
 // HIP-event bracket around one kernel launch (no-op unless si_profile_start armed the context)
 void si_prof_begin(si_ctx* ctx, const char* name, double flops, double bytes, hipStream_t st);
 void si_prof_end(si_ctx* ctx, hipStream_t st);
+// Raise a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) when a launch needs more than the
+// 64 KB default.  The high-water mark is kept per context (= per device): a process-wide cache would skip the call
+// for a second context on another GPU.
+int si_ensure_dyn_lds(si_ctx* ctx, const void* kern, size_t bytes);
 
 typedef unsigned short bf16_t;   // raw bf16 bits
 
@@ -55,7 +59,6 @@ struct TapGemmParams {
     float alpha;           // v = (acc + bias -> act -> + res) * alpha
     int accumulate;        // out = v + out
     double algo_macs;      // algorithmic multiply-accumulates of the layer (0: derive from the GEMM shape)
-    int xcd_remap;         // set by the launcher: XCD-aware workgroup-id -> tile order
     int wide_epilogue;     // set by the launcher: row-contiguous 16-byte epilogue through an LDS transpose
 };
 
@@ -64,9 +67,6 @@ static inline int si_pick_bn(int N) { return N >= 128 ? 128 : (N > 32 ? 64 : 32)
 static inline int si_round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t st);
-// ping-pong form (tapgemm_pp.hip): the two waves of a SIMD alternate MFMA and staging phases.
-// Returns SI_OK when launched, negative on error, 1 when the shape is not covered (caller uses the unified kernel).
-int si_launch_tapgemm_pp(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // encoder kernels (encoder_kernels.hip)
@@ -104,6 +104,10 @@ int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T,
 int si_launch_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,
                               const float* cb_centered /*K x D*/, const float* cb_raw /*K x D*/,
                               const float* cb_rnorm /*K*/, int K, float* mel, int Tm, int64_t* labels, hipStream_t st);
+
+// mel[b, :, pos_b + j] = cb_raw[labels[b, j]] (the expected_inpaint splice, I_ea/predict.py:177-189)
+int si_launch_codebook_gather(si_ctx* ctx, const int64_t* labels, int B, int D, const int32_t* frame_pos, int Lm,
+                              const float* cb_raw, int K, float* mel, int Tm, hipStream_t st);
 
 // k-means unit assignment: labels[row] = argmin_k ||x_row - c_k||^2 (first minimum); dist (optional) = that squared distance
 int si_launch_kmeans_assign(si_ctx* ctx, const float* x, long rows, int D, const float* cent, int K, int64_t* labels, float* dist,

@@ -586,6 +586,39 @@ int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T,
 }
 
 // ------------------------------------------------------------------------------------------------ codebook
+// arg-max with torch.argmax's rules: a NaN is the maximum, ties (and several NaNs) go to the lowest index.  The result is
+// always a valid index: every thread seeds its running best with its first candidate unconditionally, threads without
+// a candidate carry (-inf, INT_MAX) and lose every comparison against a real index.
+__device__ __forceinline__ bool argmax_better(float a, int ai, float b, int bi) {
+    const bool an = a != a, bn = b != b;
+    if (an != bn) return an;
+    if (!an && a != b) return a > b;
+    return ai < bi;
+}
+// cosine arg-max of LDS-resident row v (D floats) against the centred codebook; every thread returns the label
+__device__ __forceinline__ int codebook_argmax_128(const float* v, int D, const float* __restrict__ cc,
+                                                   const float* __restrict__ rnorm, int K, float* bs, int* bi) {
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int k = threadIdx.x; k < K; k += 128) {
+        const float* c = cc + (long)k * D;
+        float dot = 0.f;
+        for (int d = 0; d < D; ++d) dot = fmaf(v[d], c[d], dot);
+        const float sim = dot * rnorm[k];                            // ||v|| is common to all k
+        if (besti == 0x7fffffff || argmax_better(sim, k, best, besti)) { best = sim; besti = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (argmax_better(ob, oi, best, besti)) { best = ob; besti = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bs[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; }
+    __syncthreads();
+    const int lab = argmax_better(bs[1], bi[1], bs[0], bi[0]) ? bi[1] : bi[0];
+    return min(lab, K - 1);                                          // K >= 1: thread 0 always holds a real index
+}
+
 // One workgroup per (clip, masked frame).  D <= 128.
 __global__ __launch_bounds__(128) void codebook_splice_kernel(const float* __restrict__ feats, int T, int D,
                                                               const int32_t* __restrict__ frame_pos, int Lm,
@@ -597,30 +630,14 @@ __global__ __launch_bounds__(128) void codebook_splice_kernel(const float* __res
     __shared__ int bi[2];
     const int b = blockIdx.y, j = blockIdx.x;
     const int pos = frame_pos[b] + j;
-    if (pos < 0 || pos >= T) return;                                 // uniform per block
+    if (pos < 0 || pos >= T) {                                       // uniform per block: no such encoder frame
+        if (threadIdx.x == 0 && labels) labels[(long)b * Lm + j] = -1;
+        return;
+    }
     const float* f = feats + ((long)b * T + pos) * D;
     if ((int)threadIdx.x < D) v[threadIdx.x] = f[threadIdx.x];
     __syncthreads();
-    float best = -INFINITY;
-    int besti = 0x7fffffff;
-    for (int k = threadIdx.x; k < K; k += 128) {
-        const float* c = cc + (long)k * D;
-        float dot = 0.f;
-        for (int d = 0; d < D; ++d) dot = fmaf(v[d], c[d], dot);
-        const float sim = dot * rnorm[k];                            // ||v|| is common to all k
-        if (sim > best) { best = sim; besti = k; }                   // ascending k per thread: first max wins
-    }
-    // wave arg-max (ties -> lowest index, torch.argmax returns the first maximum)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(besti, o, 64);
-        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-    }
-    if ((threadIdx.x & 63) == 0) { bs[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; }
-    __syncthreads();
-    int lab = bi[0];
-    if (bs[1] > bs[0] || (bs[1] == bs[0] && bi[1] < bi[0])) lab = bi[1];
+    const int lab = codebook_argmax_128(v, D, cc, rnorm, K, bs, bi);
     if (threadIdx.x == 0 && labels) labels[(long)b * Lm + j] = lab;
     if (pos < Tm && (int)threadIdx.x < D) mel[((long)b * D + threadIdx.x) * Tm + pos] = raw[(long)lab * D + threadIdx.x];
 }
@@ -666,26 +683,8 @@ __global__ __launch_bounds__(128) void codebook_metrics_kernel(const float* __re
     const float vn = fmaxf(sqrtf(block_sum_128(vd * vd, red)), 1e-8f);
     const float cn = fmaxf(sqrtf(block_sum_128(cd * cd, red)), 1e-8f);
     const float cosvt = block_sum_128((vd / vn) * (cd / cn), red);
-    // arg-max over the centred codebook (identical to codebook_splice_kernel)
-    float best = -INFINITY;
-    int besti = 0x7fffffff;
-    for (int k = threadIdx.x; k < K; k += 128) {
-        const float* c = cc + (long)k * D;
-        float dot = 0.f;
-        for (int q = 0; q < D; ++q) dot = fmaf(v[q], c[q], dot);
-        const float sim = dot * rnorm[k];
-        if (sim > best) { best = sim; besti = k; }
-    }
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-        const float ob = __shfl_xor(best, s, 64);
-        const int oi = __shfl_xor(besti, s, 64);
-        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-    }
-    if ((threadIdx.x & 63) == 0) { bs[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; }
-    __syncthreads();
-    int lab = bi[0];
-    if (bs[1] > bs[0] || (bs[1] == bs[0] && bi[1] < bi[0])) lab = bi[1];
+    // arg-max over the centred codebook (the splice kernel's rule)
+    const int lab = codebook_argmax_128(v, D, cc, rnorm, K, bs, bi);
     const float pd = d < D ? cc[(long)lab * D + d] : 0.f;
     const float pn = fmaxf(sqrtf(block_sum_128(pd * pd, red)), 1e-8f);
     const float cospt = block_sum_128((pd / pn) * (cd / cn), red);
@@ -770,6 +769,28 @@ int si_launch_kmeans_assign(si_ctx* ctx, const float* x, long rows, int D, const
     if (rows <= 0) return SI_OK;
     si_prof_begin(ctx, "kmeans_assign", 2.0 * rows * (double)K * D, 4.0 * rows * D, st);
     hipLaunchKernelGGL(kmeans_assign_kernel, dim3((unsigned)rows), dim3(256), (size_t)D * sizeof(float), st, x, D, cent, K, labels, dist);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
+// expected_inpaint splice: given labels -> raw centroids into the mel (I_ea/predict.py:177-189)
+__global__ __launch_bounds__(128) void codebook_gather_kernel(const int64_t* __restrict__ labels, int D,
+                                                              const int32_t* __restrict__ frame_pos, int Lm,
+                                                              const float* __restrict__ raw, int K, float* __restrict__ mel, int Tm) {
+    const int b = blockIdx.y, j = blockIdx.x;
+    const int pos = frame_pos[b] + j;
+    const long lab = labels[(long)b * Lm + j];
+    if (pos < 0 || pos >= Tm || lab < 0 || lab >= K) return;
+    if ((int)threadIdx.x < D) mel[((long)b * D + threadIdx.x) * Tm + pos] = raw[lab * D + threadIdx.x];
+}
+
+int si_launch_codebook_gather(si_ctx* ctx, const int64_t* labels, int B, int D, const int32_t* frame_pos, int Lm,
+                              const float* cb_raw, int K, float* mel, int Tm, hipStream_t st) {
+    if (D > 128) return si_fail(ctx, SI_EINVAL, "codebook dim %d > 128", D);
+    if (B <= 0 || Lm <= 0) return SI_OK;
+    si_prof_begin(ctx, "codebook_gather", 0.0, 8.0 * B * Lm * D, st);
+    hipLaunchKernelGGL(codebook_gather_kernel, dim3(Lm, B), dim3(128), 0, st, labels, D, frame_pos, Lm, cb_raw, K, mel, Tm);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

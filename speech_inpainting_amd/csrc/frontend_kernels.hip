@@ -148,11 +148,7 @@ int si_launch_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const 
     if (B <= 0 || n_out <= 0) return SI_OK;
     auto kern = resample_poly_kernel;
     const size_t lds = (size_t)ntaps * sizeof(float);
-    static size_t lds_set = 0;
-    if (lds > 64 * 1024 && lds > lds_set) {
-        SI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
+    if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), lds)) return rc;
     si_prof_begin(ctx, "resample_poly", 2.0 * B * n_out * ((double)ntaps / up), 4.0 * B * ((double)n_in + n_out), st);
     hipLaunchKernelGGL(kern, dim3((n_out + 255) / 256, B), dim3(256), lds, st, x, n_in, taps, ntaps, up, down, pre_remove, n_out, y);
     si_prof_end(ctx, st);

@@ -223,11 +223,7 @@ static int respair_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t st) {
     size_t lds = ((size_t)(R1 + 50) * LD + 2 * (size_t)C * LD) * 2;
     lds = std::max(lds, (size_t)4 * 32 * 36 * sizeof(float));
     auto kern = respair_kernel<C>;
-    static size_t lds_set = 0;
-    if (lds > 64 * 1024 && lds > lds_set) {
-        SI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
+    if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), lds)) return rc;
     char name[48];
     snprintf(name, sizeof(name), "respair_f16_c%d", C);
     const double elems = (double)p.B * p.L * C;

@@ -114,15 +114,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
     // N-tiles of one M-tile are adjacent in dispatch order: they read the same activation rows, so all but the
     // first find them in L2 / Infinity Cache instead of HBM.
     const int ntn = (p.N + BN - 1) / BN;
-    // XCD-aware tile order.  Workgroup ids are dealt round-robin over the 8 XCDs (ids b and b + 8 share an L2), so with
-    // the plain id -> tile map the N-tiles of one M-tile, and M-tiles that share halo rows, sit behind eight different
-    // L2s and each fetches the shared rows again (PMC: 2.8x the algorithmic bytes on the encoder GEMMs).  The optional
-    // remap (launcher, SI_TG_XCD=1) gives every XCD label a CONTIGUOUS range of tiles (bijective for any grid size).
-    int tile = blockIdx.x;
-    if (p.xcd_remap) {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = tile & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (tile >> 3);
-    }
+    const int tile = blockIdx.x;
     const int mt = tile / ntn;
     const int seg = mt / mtiles;
     const int m0 = (mt % mtiles) * BM;
@@ -653,9 +645,8 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     const bool a16 = p.x16 != nullptr;
     // row-contiguous epilogue of the 4-waves-per-SIMD kernels: needs columns in aligned groups of four and a 4.5 KB LDS
     // patch per wave (the operand tiles are dead by then)
-    static const int wide_env = getenv("SI_TG_WIDE_EPI") ? atoi(getenv("SI_TG_WIDE_EPI")) : 1;
     constexpr bool light_cfg = WavesPerSimd<BM, BN, NT, false, true>::value == 4;
-    const bool wide = wide_env && light_cfg && a16 && !lin && p.N % 4 == 0 && p.ldo % 4 == 0 && p.ooff % 4 == 0;
+    const bool wide = light_cfg && a16 && !lin && p.N % 4 == 0 && p.ldo % 4 == 0 && p.ooff % 4 == 0;
     if (wide) lds = std::max(lds, (size_t)(NT / 64) * 32 * 36 * sizeof(float));
     void (*kern)(const TapGemmParams) = lin ? tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK, true> : tapgemm_kernel<MATH, BM, BN, WARPS_M, WARPS_N, BK, false>;
     if constexpr (MATH == SI_MATH_BF16 || MATH == SI_MATH_F16) {
@@ -663,12 +654,7 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     } else if (a16) {
         return si_fail(ctx, SI_EINVAL, "tapgemm: operand-ready (16-bit) activations need the bf16 or fp16 math mode");
     }
-    static size_t lds_set[4] = {0, 0, 0, 0};                       // per instantiation
-    const int ki = (lin ? 1 : 0) + (a16 ? 2 : 0);
-    if (lds > 64 * 1024 && lds > lds_set[ki]) {
-        SI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set[ki] = lds;
-    }
+    if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), lds)) return rc;
     const int mtiles = (p.M + BM - 1) / BM;
     dim3 grid((unsigned)(p.nseg * mtiles * ((p.N + BN - 1) / BN)), (unsigned)p.groups);
     static const char* const math_names[] = {"f32", "bf16", "bf16x3", "f16"};
@@ -679,11 +665,7 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     const double outs = (double)p.M * p.N * p.groups;
     double bytes = p.nseg * ((a16 ? 2.0 : 4.0) * p.Lin * p.Cin * p.groups + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0) + (p.res16 ? 2 : 0) + (p.accumulate ? (p.acc16 ? 2 : 4) : 0))) +
                    (double)p.groups * p.ntaps * p.N * p.Cin * (MATH == SI_MATH_F32 || MATH == SI_MATH_BF16X3 ? 4 : 2);
-    // SI_TG_XCD=1 enables the XCD-aware tile order.  Measured: no gain on any family (encoder GEMMs 4.03 vs 4.08 ms/step,
-    // narrow vocoder stages 3.21 vs 3.11): the re-fetched rows come out of the 256 MB Infinity Cache, not HBM.  Off.
-    static const int xcd_env = getenv("SI_TG_XCD") ? atoi(getenv("SI_TG_XCD")) : 0;
     TapGemmParams pk = p;
-    pk.xcd_remap = xcd_env && grid.x >= 16;
     pk.wide_epilogue = wide;
     if ((p.res16 || p.acc16) && MATH != SI_MATH_BF16 && MATH != SI_MATH_F16)
         return si_fail(ctx, SI_EINVAL, "tapgemm: 16-bit residual / accumulate exist in the bf16 and fp16 math modes only");
@@ -699,27 +681,23 @@ static int launch_math(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     const int bn = si_pick_bn(p.N);
     if (bn == 128) {
         // One 8-wave workgroup per CU on a 256x128 tile (each weight slab staged once for twice the MFMAs) instead of two
-        // 4-wave workgroups on 128x128 tiles: +6 % on the bf16x3 convolutions, +1 % in fp32 (SI_TG_BIG=0 to compare).
-        static const int big = getenv("SI_TG_BIG") ? atoi(getenv("SI_TG_BIG")) : 1;
+        // 4-wave workgroups on 128x128 tiles: +6 % on the bf16x3 convolutions, +1 % in fp32.
         const int adil8 = p.dil < 0 ? -p.dil : p.dil;
         const int cap8 = (p.ntaps == 1 ? MaxA<256, 512>::value / 2 : MaxA<256, 512>::value) * 512;
         if constexpr (MATH == SI_MATH_F16 || MATH == SI_MATH_BF16) {
             // operand-ready Linear layers (the encoder's GEMMs): eight light waves (32 x 64 each, 109 VGPRs) per 128x128
             // tile instead of four 64x64 ones (211 VGPRs) -- twice the resident waves per CU; 2.83 vs 3.12 ms/step
-            static const int lin8 = getenv("SI_TG_LIN8") ? atoi(getenv("SI_TG_LIN8")) : 1;
-            if (lin8 && p.x16 && p.ntaps == 1 && BK == 32 && p.M > 256) {
+            if (p.x16 && p.ntaps == 1 && BK == 32 && p.M > 256) {
                 // 64-deep K chunks when K allows: half the iterations (barriers, waits) per tile
-                static const int bk64 = getenv("SI_TG_BK64") ? atoi(getenv("SI_TG_BK64")) : 1;
-                if (bk64 && p.Cin % 64 == 0) return launch_cfg<MATH, 128, 128, 4, 2, 64>(ctx, p, st);
+                if (p.Cin % 64 == 0) return launch_cfg<MATH, 128, 128, 4, 2, 64>(ctx, p, st);
                 return launch_cfg<MATH, 128, 128, 4, 2, BK>(ctx, p, st);
             }
         }
-        if (big && BK == 32 && p.M > 256 && (255 * p.stride + (p.ntaps - 1) * adil8 + 1) * (BK / 4) <= cap8)
+        if (BK == 32 && p.M > 256 && (255 * p.stride + (p.ntaps - 1) * adil8 + 1) * (BK / 4) <= cap8)
             return launch_cfg<MATH, 256, 128, 4, 2, BK>(ctx, p, st);
         if constexpr (MATH == SI_MATH_F16 || MATH == SI_MATH_BF16) {
             // operand-ready convolutions whose halo rules out the 256-row tile (the encoder's stride-2 convs): light waves too
-            static const int conv8 = getenv("SI_TG_CONV8") ? atoi(getenv("SI_TG_CONV8")) : 1;
-            if (conv8 && p.x16 && p.ntaps > 1 && BK == 32 && p.M > 256 &&
+            if (p.x16 && p.ntaps > 1 && BK == 32 && p.M > 256 &&
                 (127 * p.stride + (p.ntaps - 1) * adil8 + 1) * (BK / 4) <= MaxA<128, 512>::value * 512)
                 return launch_cfg<MATH, 128, 128, 4, 2, BK>(ctx, p, st);
         }
@@ -735,9 +713,8 @@ static int launch_math(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
         // operand-ready activations, N = 64: eight light waves (32 rows x 64 columns, 92 VGPRs) per 256-row tile instead
         // of four heavy ones that spill at the 4-waves-per-SIMD budget (4.32 -> 4.20 ms/step; for N = 32 the 4-wave tile
         // stays faster: 3.11 vs 3.53)
-        static const int narrow8 = getenv("SI_TG_NARROW8") ? atoi(getenv("SI_TG_NARROW8")) : 1;
         const bool fits8 = (255 * p.stride + (p.ntaps - 1) * adil + 1) * (BK / 4) <= MaxA<256, 512>::value * 512;
-        if (narrow8 && bn == 64 && p.x16 && p.ntaps > 1 && tall && fits8 && BK == 32) return launch_cfg<MATH, 256, 64, 8, 1, BK>(ctx, p, st);
+        if (bn == 64 && p.x16 && p.ntaps > 1 && tall && fits8 && BK == 32) return launch_cfg<MATH, 256, 64, 8, 1, BK>(ctx, p, st);
     }
     if (bn == 64) return tall ? launch_cfg<MATH, 256, 64, 4, 1, BK>(ctx, p, st) : launch_cfg<MATH, 128, 64, 2, 2, BK>(ctx, p, st);
     return tall ? launch_cfg<MATH, 256, 32, 4, 1, BK>(ctx, p, st) : launch_cfg<MATH, 128, 32, 4, 1, BK>(ctx, p, st);
@@ -774,13 +751,6 @@ int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t
     if ((long)p.M * p.ldo + p.ooff < p.olimit)
         return si_fail(ctx, SI_EINVAL, "tapgemm: olimit=%ld must not exceed M*ldo+ooff=%ld (rows >= M are masked by the range check)",
                        p.olimit, (long)p.M * p.ldo + p.ooff);
-    // SI_TG_PP=1: ping-pong form (tapgemm_pp.hip): the two waves of a SIMD alternate MFMA and staging phases.
-    // Parity-green; measured 5-7 % slower than this kernel's lockstep 8-wave tile (bf16x3 14.9 vs 14.0 ms/step), opt-in.
-    static const int pingpong = getenv("SI_TG_PP") ? atoi(getenv("SI_TG_PP")) : 0;
-    if (pingpong) {
-        const int rc = si_launch_tapgemm_pp(ctx, math, p, st);
-        if (rc <= 0) return rc;
-    }
     const bool k32 = (p.Cin % 32 == 0);
     switch (math) {
         case SI_MATH_F32: return k32 ? launch_math<SI_MATH_F32, 32>(ctx, p, st) : launch_math<SI_MATH_F32, 16>(ctx, p, st);

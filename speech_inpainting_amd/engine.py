@@ -60,6 +60,10 @@ class InpaintingEngine:
     def splice(self, feats: torch.Tensor, frame_pos: torch.Tensor, lm: int, mel: torch.Tensor) -> torch.Tensor:
         return self.ctx.codebook_splice(feats, frame_pos, lm, mel)
 
+    def splice_labels(self, labels: torch.Tensor, frame_pos: torch.Tensor, mel: torch.Tensor) -> None:
+        """`expected_inpaint`'s splice (I_ea/predict.py:177-189): the raw centroids of GIVEN labels (B, Lm) into mel, in place."""
+        self.ctx.codebook_splice_labels(labels, frame_pos, mel)
+
     def vocode(self, mel: torch.Tensor, stretch: bool = True) -> torch.Tensor:
         return self.ctx.hifigan_forward(mel, stretch)
 

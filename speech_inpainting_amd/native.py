@@ -22,7 +22,7 @@ SI_MAX_CONV, SI_MAX_UPS, SI_MAX_RB, SI_MAX_DIL = 8, 8, 4, 4
 
 EXPORTS = ["si_version", "si_create", "si_destroy", "si_last_error", "si_load_weights", "si_alloc_weights",
            "si_weights_device_ptr", "si_workspace_bytes", "si_hubert_forward", "si_codebook_splice",
-           "si_codebook_metrics", "si_kmeans_assign", "si_resample_poly", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
+           "si_codebook_splice_labels", "si_codebook_metrics", "si_kmeans_assign", "si_resample_poly", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
            "si_vocoder_samples", "si_profile_start", "si_profile_filter", "si_profile_stop",
            "si_debug_capture", "si_debug_size"]
 
@@ -121,6 +121,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.si_workspace_bytes.argtypes = [vp, i32, i32, i32, C.POINTER(sz)]
     lib.si_hubert_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_codebook_splice.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp]
+    lib.si_codebook_splice_labels.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp]
     lib.si_codebook_metrics.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.si_kmeans_assign.argtypes = [vp, vp, C.c_int64, i32, vp, i32, vp, vp, vp]
     lib.si_resample_poly.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]
@@ -169,6 +170,10 @@ class NativeContext:
         self._ws: Optional[torch.Tensor] = None
 
     def close(self):
+        """Frees the context and its packed weight blob.  Any tensor from `weights_tensor()` is a VIEW of that blob and
+        must not be used after this call (the holder is dropped here so a stale view cannot be handed out again)."""
+        self._wholder = None
+        self._ws = None
         if getattr(self, "_h", None) and self._h.value:
             self.lib.si_destroy(self._h)
             self._h = C.c_void_p(0)
@@ -195,8 +200,15 @@ class NativeContext:
     def alloc_weights(self):
         self._check(self.lib.si_alloc_weights(self._h), "si_alloc_weights")
 
+    def weights_ptr(self):
+        """(device address, byte count) of the packed blob as si_weights_device_ptr reports it."""
+        p, n = C.c_void_p(0), C.c_size_t(0)
+        self._check(self.lib.si_weights_device_ptr(self._h, C.byref(p), C.byref(n)), "si_weights_device_ptr")
+        return int(p.value), int(n.value)
+
     def weights_tensor(self) -> torch.Tensor:
-        """The packed device blob as a uint8 tensor view (for the RCCL broadcast)."""
+        """The packed device blob as a uint8 tensor VIEW (for the RCCL broadcast): it aliases library-owned memory and
+        is valid only while this context is open."""
         p, n = C.c_void_p(0), C.c_size_t(0)
         self._check(self.lib.si_weights_device_ptr(self._h, C.byref(p), C.byref(n)), "si_weights_device_ptr")
 
@@ -205,11 +217,17 @@ class NativeContext:
         h = _Holder()
         h.__cuda_array_interface__ = {"shape": (n.value,), "typestr": "|u1", "data": (p.value, False), "version": 2}
         self._wholder = h
-        return torch.as_tensor(h, device=self.device)
+        t = torch.as_tensor(h, device=self.device)
+        if t.data_ptr() != p.value or t.numel() != n.value:      # as_tensor must alias, never copy
+            raise NativeError("weights_tensor: torch did not alias the library's weight blob")
+        return t
 
     # ---- shapes / workspace
     def num_frames(self, n: int) -> int:
         return int(self.lib.si_num_frames(self._h, n))
+
+    def mel_frames(self, n22: int) -> int:
+        return int(self.lib.si_mel_frames(int(n22)))
 
     def vocoder_samples(self, tm: int, stretch: bool = True) -> int:
         return int(self.lib.si_vocoder_samples(self._h, tm, int(stretch)))
@@ -249,6 +267,16 @@ class NativeContext:
         self._check(self.lib.si_codebook_splice(self._h, _ptr(feats), B, T, _ptr(frame_pos), lm, _ptr(mel), mel.shape[2],
                                                 _ptr(labels), self._stream()), "si_codebook_splice")
         return labels
+
+    def codebook_splice_labels(self, labels: torch.Tensor, frame_pos: torch.Tensor, mel: torch.Tensor) -> None:
+        """In-place splice of the raw centroids of GIVEN labels (B, Lm) int64 into `mel` (B, D, Tm)."""
+        assert labels.is_cuda and labels.dtype == torch.int64 and labels.is_contiguous() and labels.dim() == 2
+        assert mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous() and mel.dim() == 3
+        assert frame_pos.is_cuda and frame_pos.dtype == torch.int32 and frame_pos.is_contiguous()
+        B, lm = labels.shape
+        assert mel.shape[0] == B and frame_pos.numel() == B
+        self._check(self.lib.si_codebook_splice_labels(self._h, _ptr(labels), B, _ptr(frame_pos), lm, _ptr(mel), mel.shape[2],
+                                                       self._stream()), "si_codebook_splice_labels")
 
     def codebook_metrics(self, feats: torch.Tensor, frame_pos: torch.Tensor, lm: int, target: torch.Tensor):
         """-> (loss (1,), loss_terms (B, Lm), pred_labels (B, Lm) int64, cos_pred_target (B, Lm))."""
@@ -292,8 +320,6 @@ class NativeContext:
         assert D == self.desc.num_mels
         L = self.vocoder_samples(Tm, stretch)
         out = torch.empty(B, L, dtype=torch.float32, device=self.device)
-        need = C.c_size_t(0)
-        self._check(self.lib.si_workspace_bytes(self._h, B, 0, Tm, C.byref(need)), "si_workspace_bytes")
         ws = self.workspace(B, 0, Tm)
         self._check(self.lib.si_hifigan_forward(self._h, _ptr(mel), B, Tm, int(stretch), _ptr(out), _ptr(ws), ws.numel(),
                                                 self._stream()), "si_hifigan_forward")

@@ -41,9 +41,19 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
-    """In-place broadcast of the packed weight blob (uint8 view of si_weights_device_ptr, or any tensor)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(blob, src=src)
+    """In-place broadcast of the packed weight blob (uint8 view of si_weights_device_ptr, or any tensor).
+    RCCL ("nccl") broadcasts device memory directly over xGMI.  The gloo backend exists only to rehearse N > 1 ranks
+    without N GPUs (CPU tests; several ranks sharing one card): it has no device transport here, so a device blob is
+    staged through host memory around the same collective."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return blob
+    if blob.is_cuda and dist.get_backend() == "gloo":
+        host = blob.cpu()
+        dist.broadcast(host, src=src)
+        if dist.get_rank() != src:
+            blob.copy_(host)
+        return blob
+    dist.broadcast(blob, src=src)
     return blob
 
 

@@ -44,18 +44,36 @@ def build_engine(cfg: PredictConfig, device: Optional[torch.device] = None, enco
     return eng.load_state(hsd, gsd, cb)
 
 
+def check_mask_span(engine: InpaintingEngine, n16: int, n22: int, mask_pos: Sequence[int], mask_frames: int) -> None:
+    """The masked frames must exist on both sides: [pos, pos + Lm) inside the T encoder frames AND the Tm mel frames
+    (for a 4 s clip T = 199 but Tm = 200).  The reference fails on the slice-shape mismatch at I_ea/predict.py:166-168,
+    185-187; the kernels would leave such frames unspliced (label -1), so refuse here where positions are host ints."""
+    T, Tm = engine.ctx.num_frames(n16), engine.ctx.mel_frames(n22)
+    for i, p in enumerate(mask_pos):
+        if int(p) < 0 or int(p) + int(mask_frames) > min(T, Tm):
+            raise ValueError(f"clip {i}: masked frames [{int(p)}, {int(p) + int(mask_frames)}) do not fit the clip "
+                             f"({T} encoder frames, {Tm} mel frames)")
+
+
 def predict_clips(engine: InpaintingEngine, waves16: Sequence[np.ndarray], waves22: Sequence[np.ndarray],
                   mask_pos: Sequence[int], mask_frames: int, blind: bool = False,
-                  mask22: Optional[Sequence[Tuple[int, int]]] = None) -> Dict[str, torch.Tensor]:
+                  mask22: Optional[Sequence[Tuple[int, int]]] = None, diagnostics: bool = False,
+                  target_labels: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """Batch form of I_ea/predict.py:97-207 for clips of EQUAL length.
     waves16 / waves22: the same clips at 16 kHz / 22.05 kHz (float32, un-normalised), mask_pos: first masked 20 ms frame.
     mask22: per-clip [start, end) of the span zeroed on the 22.05 kHz side (predict.py:99-102: the 16 kHz sample
-    positions of the YAML times scaled by 22050 // 16000); default = the frame span."""
+    positions of the YAML times scaled by 22050 // 16000); default = the frame span.
+    diagnostics=True adds the script's other two vocoder passes as batch outputs: `hifi_masked` (the generator on the
+    masked mel alone, predict.py:123-128) and -- when `target_labels` (B, Lm) int64 ground-truth codewords are given --
+    `expected_inpaint` (their centroids spliced instead of the predicted ones, predict.py:177-189,198-201) plus the
+    codeword metrics of predict.py:171-173 (`loss`, `cos_pred_target`)."""
     dev = engine.device
     n16, n22 = len(waves16[0]), len(waves22[0])
     if any(len(w) != n16 for w in waves16) or any(len(w) != n22 for w in waves22):
         raise ValueError("clips in one batch must have equal length (group by exact length; HuBERT-base's GroupNorm "
                          "is not padding-invariant)")
+    if not blind:
+        check_mask_span(engine, n16, n22, mask_pos, mask_frames)
     wave22 = torch.from_numpy(np.stack([np.asarray(w, dtype=np.float32) for w in waves22])).to(dev)
     if blind:
         mel = engine.mel(wave22)                                                    # nothing zeroed; predict.py:104-106
@@ -69,6 +87,15 @@ def predict_clips(engine: InpaintingEngine, waves16: Sequence[np.ndarray], waves
     pos = torch.tensor(list(mask_pos), dtype=torch.int32, device=dev)
     out = engine.predict_batch(wave, mel, pos, mask_frames, blind=blind)
     out["mel_masked"] = mel
+    if diagnostics:
+        out["hifi_masked"] = engine.vocode(mel, stretch=True)
+        if target_labels is not None and not blind:
+            tgt = target_labels.to(dev, torch.int64).contiguous()
+            exp = mel.clone()
+            engine.splice_labels(tgt, pos, exp)
+            out["expected_inpaint"] = engine.vocode(exp, stretch=True)
+            m = engine.codebook_metrics(out["feats"], pos, mask_frames, tgt)
+            out["loss"], out["cos_pred_target"] = m["loss"], m["cos_pred_target"]
     return out
 
 
@@ -124,23 +151,18 @@ def main(argv=None) -> int:
     audio.write_wav(os.path.join(save_dir, "masked.wav"), masked_16, 16000)
 
     span22 = (cfg.start_sample * 22050 // 16000, cfg.end_sample * 22050 // 16000)   # predict.py:99-100
-    out = predict_clips(engine, [wave_16], [wave_22], [pos], lm, mask22=[span22])
-    # hifi_masked.wav: the vocoder on the masked mel alone (predict.py:123-128)
-    hm = engine.vocode(out["mel_masked"], stretch=True)
-    audio.write_wav(os.path.join(save_dir, "hifi_masked.wav"), audio.to_int16_pcm(hm[0]), 22050)
     labels_path = os.path.join(cfg.path2centroids, wave_name + "_labels.pt")
-    if os.path.exists(labels_path):                                                # predict.py:160-161,177-189,198-201
-        from .checkpoint import load_codebook as _cb
+    labels = None
+    if os.path.exists(labels_path):                                                # predict.py:160-161
         labels = torch.load(labels_path, map_location="cpu").t().reshape(-1)[pos:pos + lm].long()
-        cb = _cb(cfg.km_model_path)
-        exp = out["mel_masked"].clone()
-        exp[0, :, pos:pos + lm] = cb[labels].T.to(exp.device)
-        ew = engine.vocode(exp, stretch=True)
-        audio.write_wav(os.path.join(save_dir, "expected_inpaint.wav"), audio.to_int16_pcm(ew[0]), 22050)
-        m = engine.codebook_metrics(out["feats"], torch.tensor([pos], dtype=torch.int32, device=engine.device), lm,
-                                    labels[None].to(engine.device))                 # predict.py:171-173
-        print("Loss:", float(m["loss"]))
-        print("Average Cosine Similarity: ", float(m["cos_pred_target"].mean()))
+    out = predict_clips(engine, [wave_16], [wave_22], [pos], lm, mask22=[span22], diagnostics=True,
+                        target_labels=None if labels is None else labels[None])
+    # hifi_masked.wav: the vocoder on the masked mel alone (predict.py:123-128)
+    audio.write_wav(os.path.join(save_dir, "hifi_masked.wav"), audio.to_int16_pcm(out["hifi_masked"][0]), 22050)
+    if labels is not None:                                                         # predict.py:171-189,198-201
+        audio.write_wav(os.path.join(save_dir, "expected_inpaint.wav"), audio.to_int16_pcm(out["expected_inpaint"][0]), 22050)
+        print("Loss:", float(out["loss"]))
+        print("Average Cosine Similarity: ", float(out["cos_pred_target"].mean()))
         print("Target codewords: ", labels.tolist())
     print("Predicted codewords: ", out["labels"][0].tolist())
     audio.write_wav(os.path.join(save_dir, "inpainted.wav"), audio.to_int16_pcm(out["wave"][0]), 22050)

@@ -37,9 +37,7 @@ COMBOS = [
     {"SI_VOC_FUSE": "0"},                                    # fp16 stream with the conv pairs as two launches
     {"SI_VOC_OPREADY": "0", "SI_ENC_OPREADY": "0"},         # consumers convert fp32 activations while staging
     {"SI_ATT_BF16": "0"},                                    # bf16 encoder with the exact-fp32 attention kernel
-    {"SI_TG_WIDE_EPI": "0"},                                 # per-lane scalar epilogue in the light kernels
-    {"SI_TG_PP": "1", "SI_TG_XCD": "1"},                     # ping-pong kernel variant + XCD-aware tile order
-    {"SI_TG_BIG": "0", "SI_TG_LIN8": "0", "SI_TG_CONV8": "0", "SI_TG_NARROW8": "0", "SI_TG_BK64": "0"},   # the older tile shapes
+    {"SI_VOC_RES16": "0", "SI_VOC_OPREADY": "0", "SI_ENC_OPREADY": "0", "SI_ATT_BF16": "0"},   # every non-default arithmetic path at once
 ]
 
 
@@ -56,4 +54,4 @@ def test_knob_combination_stays_parity_green(combo):
     assert r["x3"]["labels"] and r["x3"]["err"] <= 1e-5
     assert r["fp16"]["labels"] and r["fp16"]["err"] <= 2e-4
     assert r["bf16"]["labels"] and r["bf16"]["err"] <= 1e-3
-    assert r["enc_bf16"]["feat_rel"] <= 5e-2
+    assert r["enc_bf16"]["feat_rel"] <= 2e-2

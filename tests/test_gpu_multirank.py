@@ -1,0 +1,63 @@
+"""N > 1 ranks with the REAL engine, rehearsed on the one GPU of the test box: rank 0 reads the
+checkpoint, the other ranks allocate the packed blob (si_alloc_weights) and receive it by the broadcast, every rank runs
+its utterance shard, metrics come back by the all-gather.  The 8-GPU run differs only in the backend string."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(nproc, script_args, timeout=900):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_args
+    return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("nproc,enc,voc", [(2, "fp32", "fp32"), (3, "bf16", "fp16")])
+def test_ranks_share_one_gpu_and_match_the_single_batch_run(nproc, enc, voc):
+    p = _launch(nproc, [os.path.join(ROOT, "tests", "rank_worker.py"), enc, voc])
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    line = [l for l in p.stdout.splitlines() if l.startswith("RANKS_OK ")][-1]
+    r = json.loads(line[len("RANKS_OK "):])
+    assert r["ok"] and r["world"] == nproc and sum(r["clips"]) == 7
+
+
+def test_bench_two_rank_rehearsal_prints_the_contract_line():
+    """bench.py --gpus 2 launched exactly as the driver launches it, but with SI_DIST_BACKEND=gloo so two ranks can share
+    this box's GPU (small batch: the point is the rendezvous, the broadcast into si_alloc_weights memory, the barrier /
+    max-over-ranks timing and the JSON line)."""
+    env_backend = os.environ.get("SI_DIST_BACKEND")
+    os.environ["SI_DIST_BACKEND"] = "gloo"
+    try:
+        p = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--no-fp32-leg", "--cpu-clips", "0"])
+    finally:
+        if env_backend is None:
+            os.environ.pop("SI_DIST_BACKEND", None)
+        else:
+            os.environ["SI_DIST_BACKEND"] = env_backend
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 8 and r["scaling"] == "weak"
+    assert r["value"] > 0 and r["steps"] == 2 and "roofline" in r
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "rehearsal_2rank.json"), "w") as f:
+        f.write(line + "\n")

@@ -79,22 +79,159 @@ def test_stage_taps_match_oracle(name):
         assert rms(got, ref) <= 2e-5 * max(rms(ref), 1.0), nm
 
 
+def _masked_wave_span(c, margin_frames=16):
+    """Waveform samples that can depend on the spliced mel frames: the masked frames after the x441/256 stretch, widened
+    by the generator's receptive field (conv_pre 3 frames + MRF halos 60 rows per stage = 1920 + 240 + 120 + 60 samples
+    + upsamplers: < 14 stretched frames per side)."""
+    m = c["meta"]
+    lo = min(c["frame_pos"]) * 441 // 256 - margin_frames
+    hi = (max(c["frame_pos"]) + m["lm"]) * 441 // 256 + 1 + margin_frames
+    return max(lo, 0) * 256, hi * 256
+
+
+# measured on MI355X (round 2): feats relative rms error and label agreement of the bf16 encoder against the reference's
+# fp32 goldens; the asserted bounds are 2x the measured error / the measured agreement floor
+BF16_FEAT_REL = {"base_4s": 2e-2, "large_4s": 2e-2, "tiny_layer": 2e-2, "tiny_group": 2e-2}
+BF16_AGREE_FLOOR = {"base_4s": 0.8, "large_4s": 0.8, "tiny_layer": 0.8, "tiny_group": 0.8}
+
+
+def _check_wave(name, c, out, gate):
+    """Waveform vs the golden: whole clip when every label agrees, otherwise everything OUTSIDE the receptive field of
+    the spliced frames (a flipped codeword legitimately changes the samples it reaches)."""
+    z = c["z"]
+    agree = float((out["labels"].numpy() == z["labels"]).mean())
+    lo, hi = _masked_wave_span(c)
+    if "wave" in z.files:
+        ref, got = torch.from_numpy(z["wave"]), out["wave"]
+        if agree == 1.0:
+            err, where = rms(got, ref), "whole clip"
+        else:
+            err = max(rms(got[:, :lo], ref[:, :lo]) if lo > 0 else 0.0, rms(got[:, hi:], ref[:, hi:]) if hi < ref.shape[1] else 0.0)
+            where = f"outside samples [{lo}, {hi})"
+    else:     # large_4s stores the first / last 2048 samples, both outside the masked span's receptive field
+        assert lo >= 2048 and hi <= out["wave"].shape[1] - 2048
+        err, where = max(rms(out["wave"][:, :2048], z["wave_head"]), rms(out["wave"][:, -2048:], z["wave_tail"])), "head + tail"
+    print(f"{name}: label agreement {agree:.2f}, waveform rms error {err:.3e} ({where}; signal rms {float(z['wave_rms']):.3f})")
+    assert err <= gate, (name, err, where)
+    return agree, err
+
+
 @pytest.mark.parametrize("name", ["base_4s", "large_4s", "tiny_layer", "tiny_group"])
-def test_bf16_encoder_mode_reports_label_agreement(name):
-    """BASELINE config #2 arithmetic: bf16 MFMA encoder (fp32 accumulate, fp32 head) with operand-ready bf16
+def test_bf16_encoder_mode_label_agreement_and_waveform(name):
+    """BASELINE config #2 encoder arithmetic: bf16 MFMA encoder (fp32 accumulate, fp32 head) with operand-ready bf16
     activations, on the post-LN / group-norm flavour (base, tiny_group) and the pre-LN / layer-norm flavour (large,
-    tiny_layer).  The arg-max in the middle of the path is a discrete decision, so agreement is reported rather than
-    required to be 1."""
+    tiny_layer), fp32 vocoder.  The arg-max in the middle of the path is a discrete decision: agreement has a stated
+    floor, and the waveform is held to the 1e-3 gate wherever the labels cannot reach it."""
     c = load_case(name)
     z = c["z"]
     out = _run(_engine(c, enc="bf16"), c)
     feats_ref = torch.from_numpy(z["feats"])
     rel = rms(out["feats"], feats_ref) / rms(feats_ref)
-    agree = float((out["labels"].numpy() == z["labels"]).mean())
-    print(f"{name} bf16 encoder: feats relative rms error {rel:.3e}, label agreement {agree:.2f}")
-    assert rel <= 5e-2
-    if agree == 1.0 and "wave" in z.files:
-        assert rms(out["wave"], z["wave"]) <= 1e-3
+    print(f"{name} bf16 encoder: feats relative rms error {rel:.3e}")
+    assert rel <= BF16_FEAT_REL[name]
+    agree, _ = _check_wave(name + " bf16/fp32", c, out, 1e-3)
+    assert agree >= BF16_AGREE_FLOOR[name]
+
+
+@pytest.mark.parametrize("name", ["base_4s", "large_4s", "tiny_group"])
+def test_headline_arithmetic_against_reference_goldens(name):
+    """The benchmark's own arithmetic END TO END -- bf16 encoder + fp16 vocoder with the fp16 activation stream and the
+    fused ResBlock kernels -- against the outputs of the reference's fp32 modules (I_ea/predict.py:163-207): label
+    agreement >= the stated floor, waveform RMS error <= 1e-3 (the north-star gate) on every sample the labels that
+    agree can reach (the whole clip when all agree)."""
+    c = load_case(name)
+    out = _run(_engine(c, enc="bf16", voc="fp16"), c)
+    agree, err = _check_wave(name + " bf16/fp16 (headline)", c, out, 1e-3)
+    assert agree >= BF16_AGREE_FLOOR[name]
+    assert bool(torch.isfinite(out["wave"]).all())
+
+
+def test_nan_sample_does_not_fault_and_labels_stay_in_range():
+    """A NaN sample in the clip (float WAVs can hold them) makes every feature NaN; torch.argmax then returns an in-range
+    index (NaN counts as the maximum, first one wins -> 0).  The kernel must do the same instead of indexing the
+    codebook with an uninitialised label."""
+    c = load_case("tiny_group")
+    m = c["meta"]
+    eng = _engine(c)
+    wave = c["wave"].clone()
+    wave[1, 1234] = float("nan")
+    pos = torch.tensor(c["frame_pos"], dtype=torch.int32, device="cuda")
+    out = eng.predict_batch(wave.cuda(), c["mel"].cuda(), pos, m["lm"])
+    torch.cuda.synchronize()
+    lab = out["labels"].cpu()
+    assert int(lab.min()) >= 0 and int(lab.max()) < m["K"]
+    assert bool((lab[1] == 0).all())                                   # all-NaN similarities: first index, as torch.argmax
+    assert np.array_equal(lab[0].numpy(), c["z"]["labels"][0]) and np.array_equal(lab[2].numpy(), c["z"]["labels"][2])
+
+
+def test_mask_past_the_last_frame_yields_label_minus_one():
+    """frame_pos + Lm beyond T: the reference fails on the slice-shape mismatch (I_ea/predict.py:166-168); the kernel
+    marks such frames -1 and leaves the mel column alone, and predict_clips refuses the call on the host."""
+    from speech_inpainting_amd.predict import check_mask_span
+    c = load_case("tiny_group")
+    m = c["meta"]
+    eng = _engine(c)
+    feats = eng.encode(c["wave"].cuda())
+    pos = torch.tensor([m["T"] - 3] * m["B"], dtype=torch.int32, device="cuda")
+    mel = c["mel"].cuda().clone()
+    lab = eng.splice(feats, pos, 5, mel).cpu()
+    assert bool((lab[:, :3] >= 0).all()) and bool((lab[:, 3:] == -1).all())
+    assert torch.equal(mel[:, :, :m["T"] - 3].cpu(), c["mel"][:, :, :m["T"] - 3])
+    with pytest.raises(ValueError, match="do not fit"):
+        check_mask_span(eng, m["N"], 11264, [m["T"] - 3], 5)
+
+
+def test_receiving_rank_weight_path_on_one_gpu():
+    """The multi-GPU receive side without a second GPU: engine B allocates the packed blob
+    (si_alloc_weights), the bytes arrive by a device copy standing in for the RCCL broadcast, and B must then compute
+    bit-identically to the engine that read the checkpoint.  Also pins that the torch view aliases the library's blob
+    and that the layout is a pure function of the model desc (equal size in both contexts)."""
+    from speech_inpainting_amd.engine import InpaintingEngine
+    c = load_case("tiny_group")
+    m = c["meta"]
+    for enc, voc in (("fp32", "fp32"), ("bf16", "fp16")):
+        A = _engine(c, enc=enc, voc=voc)
+        B = InpaintingEngine(c["harch"], c["varch"], m["K"], "cuda:0", enc, voc).alloc_weights()
+        wa, wb = A.weights_tensor(), B.weights_tensor()
+        pa, na = A.ctx.weights_ptr()
+        pb, nb = B.ctx.weights_ptr()
+        assert wb.data_ptr() == pb and wb.numel() == nb and wa.data_ptr() == pa and na == nb and pa != pb
+        assert wb.dtype == torch.uint8 and wb.is_cuda
+        wb.copy_(wa)
+        torch.cuda.synchronize()
+        oa, ob = _run(A, c), _run(B, c)
+        assert torch.equal(oa["labels"], ob["labels"]) and torch.equal(oa["wave"], ob["wave"]) and torch.equal(oa["feats"], ob["feats"])
+        del wa, wb
+        A.ctx.close(); B.ctx.close()
+
+
+def test_expected_inpaint_and_hifi_masked_batch_outputs():
+    """predict_clips(diagnostics=True): the script's other two vocoder passes (I_ea/predict.py:123-128,177-189,198-201)
+    as batch outputs, against the oracle's generator on the same mels."""
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.predict import predict_clips
+    c = load_case("tiny_group")
+    m = c["meta"]
+    eng = _engine(c)
+    n22 = m["N"] * 22050 // 16000
+    w16 = [c["wave"][i].numpy() for i in range(m["B"])]
+    w22 = [synth.synth_wave(1, n22, 70 + i, sr=22050)[0].numpy() for i in range(m["B"])]
+    Tm = eng.ctx.mel_frames(n22)
+    lm = 4
+    pos = [2, 5, min(m["T"], Tm) - lm]
+    tgt = torch.tensor([[1, 2, 3, 4], [5, 6, 7, 8], [99, 0, 50, 10]], dtype=torch.int64)
+    out = predict_clips(eng, w16, w22, pos, lm, diagnostics=True, target_labels=tgt)
+    torch.cuda.synchronize()
+    mel = out["mel_masked"].cpu()
+    hm = R.generator_forward(c["gsd"], c["varch"], R.extend_mel(mel))[:, 0, :]
+    assert rms(out["hifi_masked"].cpu(), hm) <= 1e-5
+    exp = mel.clone()
+    for i in range(m["B"]):
+        exp[i, :, pos[i]:pos[i] + lm] = c["cb"][tgt[i]].T
+    ew = R.generator_forward(c["gsd"], c["varch"], R.extend_mel(exp))[:, 0, :]
+    assert rms(out["expected_inpaint"].cpu(), ew) <= 1e-5
+    assert out["cos_pred_target"].shape == (m["B"], lm) and bool(torch.isfinite(out["loss"]))
 
 
 @pytest.mark.parametrize("name,voc,tol", [("tiny_group", "bf16x3", 1e-5), ("base_4s", "bf16x3", 1e-5), ("large_4s", "bf16x3", 1e-5),

@@ -137,7 +137,19 @@ int si_launch_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const 
                             int pre_remove, int n_out, float* y, hipStream_t st);
 
 // One ResBlock1 step y' = (y + conv2(lrelu(conv1(lrelu(y)) + b1)) + b2) * alpha [+ previous y'] as one kernel on the raw
-// fp16 activation stream (respair.hip; C = 32 / 64).  Returns 1 when the shape is not covered.
+// fp16 activation stream (respair.hip: C = 32 / 64; respair_wide.hip: C = 128 / 256).  Returns 1 when the shape is not covered.
+struct ResPairParams {
+    const unsigned short* y16;   // [B][L][C] raw fp16 activation stream (input and residual)
+    unsigned short* out16;       // [B][L][C] raw fp16
+    const unsigned short* w1;    // [k][C][C] fp16 (tap, n, ci)
+    const unsigned short* w2;
+    const float* b1;
+    const float* b2;
+    int B, L, k, dil;
+    float alpha;                 // out = (conv2 + b2 + y) * alpha
+    int accumulate;              // out += previous out16
+};
+int si_launch_respair_wide(si_ctx* ctx, int C, const ResPairParams& p, hipStream_t st);
 int si_launch_respair(si_ctx* ctx, int C, const unsigned short* y16, unsigned short* out16, const void* w1, const void* w2,
                       const float* b1, const float* b2, int B, int L, int k, int dil, float alpha, int accumulate, hipStream_t st);
 

@@ -28,18 +28,6 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-struct ResPairParams {
-    const unsigned short* y16;   // [B][L][C] raw fp16 activation stream (input and residual)
-    unsigned short* out16;       // [B][L][C] raw fp16
-    const unsigned short* w1;    // [k][C][C] fp16 (tap, n, ci)
-    const unsigned short* w2;
-    const float* b1;
-    const float* b2;
-    int B, L, k, dil;
-    float alpha;                 // out = (conv2 + b2 + y) * alpha
-    int accumulate;              // out += previous out16
-};
-
 template <int C>
 __global__ __launch_bounds__(256, 3) void respair_kernel(const ResPairParams p) {
     constexpr int R1 = 256;                              // intermediate rows per workgroup
@@ -237,8 +225,10 @@ static int respair_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t st) {
 // SI_OK when launched, negative on error, 1 when the shape is not covered (the caller launches the two convolutions).
 int si_launch_respair(si_ctx* ctx, int C, const unsigned short* y16, unsigned short* out16, const void* w1, const void* w2,
                       const float* b1, const float* b2, int B, int L, int k, int dil, float alpha, int accumulate, hipStream_t st) {
-    if ((C != 32 && C != 64) || k < 2 || k > 11 || (k & 1) == 0 || (k - 1) * dil > 50 || (long)L * C * 2 >= (1L << 31)) return 1;
+    if ((C != 32 && C != 64 && C != 128 && C != 256) || k < 3 || k > 11 || (k & 1) == 0 || (k - 1) * dil > 50 ||
+        ((long)L + 512) * C * 2 >= (1L << 31)) return 1;
     if (!b1 || !b2) return 1;
     ResPairParams p{y16, out16, static_cast<const unsigned short*>(w1), static_cast<const unsigned short*>(w2), b1, b2, B, L, k, dil, alpha, accumulate};
+    if (C >= 128) return si_launch_respair_wide(ctx, C, p, st);
     return C == 32 ? respair_launch<32>(ctx, p, st) : respair_launch<64>(ctx, p, st);
 }

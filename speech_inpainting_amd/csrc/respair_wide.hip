@@ -1,0 +1,294 @@
+// respair_wide.hip -- one ResBlock1 step  y' = y + conv2(lrelu(conv1(lrelu(y))))  as ONE kernel for the WIDE vocoder
+// stages (C = 128 / 256 channels) in the fp16 activation-stream mode (gfx950, wave64, MFMA).
+//
+// I_ea/hifi_gan/models.py:36-43 runs, per (resblock, dilation): xt = lrelu(x); xt = c1(xt); xt = lrelu(xt); xt = c2(xt);
+// x = xt + x; the MRF mean over the three resblocks is :112-118.  The wide stages carry 2/3 of the path's FLOPs.  As two
+// tap-GEMM launches each convolution paid its own cold prologue and output burst per 256x128 tile and the pair's
+// intermediate made a round trip through HBM / L2; here one 8-wave workgroup owns R1 rows x ALL C channels and keeps the
+// intermediate in LDS:
+//   prologue  the halo'd activation tile (R1 + (k-1)(d+... rows, all channels) is loaded ONCE, leaky-ReLU'd on the packed
+//             halves and staged into LDS
+//   phase 1   t[R1 rows] = lrelu(conv1(lrelu(y)) + b1), zero outside the clip (conv2's padding applies to t), rounded
+//             to fp16 and written OVER the activation tile (dead once conv1 is done)
+//   phase 2   acc[R1 rows] = conv2(t); rows >= R1 - (k-1) are recomputed by the neighbouring tile
+//   epilogue  the fp32 accumulators go through an LDS image of the output tile (everything else is dead), then
+//             out = (acc + b2 + y) * alpha (+ previous out) is computed and stored row-contiguously: 16 bytes per lane,
+//             whole 256 / 512-byte rows per wave instruction, residual / accumulate reads in the same shape
+// Weight slabs ([C n][BKW ci] of one tap: 32 KB) stream L2 -> registers -> LDS through a double buffer, one workgroup
+// barrier per slab; a slab feeds 32 (C = 128) / 16 (C = 256) MFMAs per wave, against 8 per barrier in the tap-GEMM.
+//
+// MFMA orientation: D^T = W * Y^T (v_mfma_f32_32x32x16_f16 with the WEIGHT rows as the A operand): a lane then holds one
+// time row (column l&31) and, in registers 4g..4g+3, four CONSECUTIVE channels -- so the intermediate is written to LDS
+// with 8-byte stores and the output image with 16-byte stores, no shuffles.
+//
+// LDS images are unpadded; 16-byte chunk c of row r lives at chunk c ^ f(r) (f = r & 15 for rows >= 256 bytes,
+// (r >> 1) & 7 for 128-byte rows), which spreads the 16 rows of a ds_read_b128 lane group over all 16 four-bank slots.
+// The XOR costs one VALU op per fragment read: pre = row base | ((f(r) ^ lane half) << 4) per (fragment row, tap), then
+// address = pre ^ (k-step * 32).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int ROWB>
+__device__ __forceinline__ int swz16(int row) {                        // (chunk XOR term of a row) << 4
+    if constexpr (ROWB >= 256) return (row & 15) << 4;
+    else return ((row >> 1) & 7) << 4;                                // 128-byte rows: two rows per 256-byte bank period
+}
+
+constexpr int RPW_HALO = 50;                                          // (k - 1) * dil <= 50: k = 11, dil = 5
+
+template <int C, int R1, int WARPS_M, int WARPS_N, int BKW>
+__global__ __launch_bounds__(512, 2) void respair_wide_kernel(const ResPairParams p) {
+    static_assert(WARPS_M * WARPS_N == 8 && R1 == WARPS_M * 64 && C == WARPS_N * 64, "8 waves, 64 x 64 wave tiles");
+    static_assert(BKW == 128 || BKW == 64, "weight-slab depth");
+    constexpr int NT = 512;
+    constexpr int ROWBY = C * 2;                                       // bytes per activation / intermediate row
+    constexpr int ROWBW = BKW * 2;                                     // bytes per weight-slab row
+    constexpr int ROWBO = C * 4;                                       // bytes per fp32 output-image row
+    constexpr int CPRY = C / 8, CPRW = BKW / 8;                        // 16-byte chunks per row
+    constexpr int NCH = C / BKW;                                       // weight slabs per tap
+    constexpr int KS = BKW / 16;                                       // MFMA k-steps per slab
+    constexpr int YBYTES = (R1 + RPW_HALO) * ROWBY;
+    constexpr int WBYTES = C * ROWBW;
+    constexpr int WSLOTS = C * CPRW / NT;
+    constexpr int YSLOTS = ((R1 + RPW_HALO) * CPRY + NT - 1) / NT;
+    constexpr int YRPP = NT / CPRY, WRPP = NT / CPRW;                  // rows per staging pass
+    static_assert(C * CPRW % NT == 0 && NT % CPRY == 0 && NT % CPRW == 0, "staging maps");
+    static_assert(R1 * ROWBO <= YBYTES + 2 * WBYTES, "the output image reuses the operand region (not the biases behind it)");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Ys = smem;                                             // [R1 + 50][C] fp16: lrelu(y), later t (rows < R1)
+    char* const Ws = smem + YBYTES;                                    // [2][C][BKW] fp16 weight slabs
+    float* const Bs = reinterpret_cast<float*>(smem + YBYTES + 2 * WBYTES);   // [2][C] fp32: b1, b2 (outside the output image)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm0 = (wave / WARPS_N) * 64, wn0 = (wave % WARPS_N) * 64;
+    const int k = p.k, d = p.dil;
+    const int p1 = d * (k - 1) / 2, p2 = (k - 1) / 2;
+    const int BMo = R1 - (k - 1);
+    const int R0 = R1 + (k - 1) * d;
+    const int b = blockIdx.y;
+    const int m0 = blockIdx.x * BMo;                                   // first output row of this workgroup
+    const int t_row0 = m0 - p2;                                        // clip row of intermediate row 0
+    const int y_row0 = t_row0 - p1;                                    // clip row of staged activation row 0
+
+    const long seg = (long)b * p.L * C;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + seg), 0, p.L * C * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out16 + seg, 0, p.L * C * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w1), 0, k * C * C * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w2), 0, k * C * C * 2, 0x00020000);
+
+    // ---- weight slabs: slab s = (conv, tap, chunk) in that order; conv 1 first
+    const int NS1 = k * NCH, NS = 2 * NS1;
+    const int wc = tid % CPRW, wr0 = tid / CPRW;
+    u32x4 rw[WSLOTS];
+    auto issueW = [&](int s) {
+        const bool second = s >= NS1;
+        const int q = second ? s - NS1 : s;
+        const int tap = q / NCH, ch = q - tap * NCH;
+        // readfirstlane: the slab offset is wave-uniform, but the compiler cannot always prove it and would wrap every
+        // load in a waterfall loop
+        const int soff = __builtin_amdgcn_readfirstlane((tap * C * C + ch * BKW) * 2);
+#pragma unroll
+        for (int i = 0; i < WSLOTS; ++i) {
+            const int n = wr0 + i * WRPP;
+            rw[i] = __builtin_amdgcn_raw_buffer_load_b128(second ? w2rsrc : w1rsrc, (n * C + 8 * wc) * 2, soff, 0);
+        }
+    };
+    auto storeW = [&](char* dst) {
+#pragma unroll
+        for (int i = 0; i < WSLOTS; ++i) {
+            const int n = wr0 + i * WRPP;
+            *reinterpret_cast<u32x4*>(dst + n * ROWBW + ((wc << 4) ^ swz16<ROWBW>(n))) = rw[i];
+        }
+    };
+
+    issueW(0);
+    if (tid < C / 2) {                                                 // biases -> LDS: the epilogues read them per lane
+        const int which = tid / (C / 4), c4 = (tid % (C / 4)) * 4;
+        *reinterpret_cast<f32x4*>(Bs + which * C + c4) = *reinterpret_cast<const f32x4*>((which ? p.b2 : p.b1) + c4);
+    }
+    // ---- the activation tile: raw fp16 -> leaky-ReLU(0.1) on the packed halves -> LDS (rows outside the clip read as zero)
+    {
+        const int yc = tid % CPRY, yr0 = tid / CPRY;
+        u32x4 ry[YSLOTS];
+#pragma unroll
+        for (int i = 0; i < YSLOTS; ++i)
+            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, ((y_row0 + yr0 + i * YRPP) * C + 8 * yc) * 2, 0, 0);
+        storeW(Ws);                                                    // slab 0 has landed; the tile is still in flight
+        issueW(NS > 1 ? 1 : 0);
+#pragma unroll
+        for (int i = 0; i < YSLOTS; ++i) {
+            const int r = yr0 + i * YRPP;
+            if (r < R0) {
+                f16x8 h = __builtin_bit_cast(f16x8, ry[i]);
+                const f16x8 hs = h * (_Float16)0.1f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = h[e] > (_Float16)0 ? h[e] : hs[e];
+                *reinterpret_cast<f16x8*>(Ys + r * ROWBY + ((yc << 4) ^ swz16<ROWBY>(r))) = h;
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];                                                  // [time tile i][channel tile j], transposed tiles
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
+    int preW[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = wn0 + 32 * j + l31;
+        preW[j] = n * ROWBW + (swz16<ROWBW>(n) ^ (half << 4));
+    }
+    // one slab: acc^T += W[slab] * A[rows + roff][chunk columns]^T
+    auto compute = [&](int roff, int cb16, const char* Wc) {
+        int preY[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wm0 + 32 * i + l31 + roff;
+            preY[i] = r * ROWBY + (((r & 15) ^ half) << 4);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            f16x8 y[2], w[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) y[i] = *reinterpret_cast<const f16x8*>(Ys + (preY[i] ^ (cb16 + ks * 32)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) w[j] = *reinterpret_cast<const f16x8*>(Wc + (preW[j] ^ (ks * 32)));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[j], y[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    int tap = 0, ch = 0;                                               // of slab s within its convolution
+    for (int s = 0; s < NS; ++s) {
+        const bool second = s >= NS1;
+        compute(second ? tap : tap * d, ch * (BKW * 2), Ws + (s & 1) * WBYTES);
+        if (s == NS1 - 1) {
+            __syncthreads();                                           // every wave has finished reading the activation tile
+            // ---- phase-1 epilogue: bias, leaky-ReLU, zero outside the clip, fp16, over the activation tile
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = wm0 + 32 * i + l31;
+                const int grow = t_row0 + m;
+                const bool inside = grow >= 0 && grow < p.L;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = wn0 + 32 * j + 8 * g + 4 * half;
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(Bs + n);
+                        f16x4 hv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[i][j][4 * g + e] + bv[e];
+                            v = v > 0.f ? v : 0.1f * v;
+                            v = inside ? __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f) : 0.f;
+                            hv[e] = (_Float16)v;
+                        }
+                        *reinterpret_cast<f16x4*>(Ys + m * ROWBY + ((((n >> 3) ^ (m & 15)) << 4) + 8 * half)) = hv;
+                    }
+            }
+            zero_acc();
+        }
+        if (++ch == NCH) { ch = 0; if (++tap == k) tap = 0; }
+        if (s + 1 < NS) {
+            storeW(Ws + ((s + 1) & 1) * WBYTES);                       // slab s + 1, in flight since the previous iteration
+            issueW(s + 2 < NS ? s + 2 : NS - 1);                       // unconditional: a conditional load drains vmcnt at the join
+            __syncthreads();
+        }
+    }
+
+    // ---- final epilogue: accumulators -> fp32 image of the output tile in LDS -> row-contiguous residual add + store
+    __syncthreads();                                                   // every wave is done with the operand tiles
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = wm0 + 32 * i + l31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = ((wn0 + 32 * j) >> 2) + 2 * g + half;   // 16-byte chunk (4 channels) of the output row
+                const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(smem + m * ROWBO + ((co ^ (m & 15)) << 4)) = v;
+            }
+    }
+    __syncthreads();
+    {
+        constexpr int ORPP = NT / CPRY;                                // output rows per pass: a lane owns 8 channels of a row
+        constexpr int OPASS = R1 / ORPP;
+        const int c8 = tid % CPRY, or0 = tid / CPRY;
+        const f32x4 b2a = *reinterpret_cast<const f32x4*>(Bs + C + 8 * c8), b2b = *reinterpret_cast<const f32x4*>(Bs + C + 8 * c8 + 4);
+        u32x4 res[OPASS], prev[OPASS];
+        int goff[OPASS];
+#pragma unroll
+        for (int it = 0; it < OPASS; ++it) {
+            const int o = or0 + it * ORPP;
+            const int grow = m0 + o;
+            goff[it] = (o < BMo && grow < p.L) ? (grow * C + 8 * c8) * 2 : (int)0x80000000;
+            res[it] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, goff[it], 0, 0);
+            if (p.accumulate) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, goff[it], 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < OPASS; ++it) {
+            const int o = or0 + it * ORPP;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + o * ROWBO + (((2 * c8) ^ (o & 15)) << 4));
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem + o * ROWBO + (((2 * c8 + 1) ^ (o & 15)) << 4));
+            const f16x8 rh = __builtin_bit_cast(f16x8, res[it]);
+            f16x8 ph = {};
+            if (p.accumulate) ph = __builtin_bit_cast(f16x8, prev[it]);
+            f16x8 out;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = e < 4 ? a0[e] : a1[e - 4];
+                const float bb = e < 4 ? b2a[e] : b2b[e - 4];
+                float v = (a + bb + (float)rh[e]) * p.alpha;
+                if (p.accumulate) v += (float)ph[e];
+                out[e] = (_Float16)__builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out), orsrc, goff[it], 0, 0);
+        }
+    }
+}
+
+template <int C, int R1, int WARPS_M, int WARPS_N, int BKW>
+static int respair_wide_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t st) {
+    const int BMo = R1 - (p.k - 1);
+    const size_t lds = (size_t)(R1 + RPW_HALO) * C * 2 + 2 * (size_t)C * BKW * 2 + 2 * (size_t)C * 4;
+    auto kern = respair_wide_kernel<C, R1, WARPS_M, WARPS_N, BKW>;
+    if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), lds)) return rc;
+    char name[48];
+    snprintf(name, sizeof(name), "respair_f16_c%d", C);
+    const double elems = (double)p.B * p.L * C;
+    si_prof_begin(ctx, name, 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 2.0 * 2.0 * p.k * C * C, st);
+    hipLaunchKernelGGL(kern, dim3((p.L + BMo - 1) / BMo, p.B), dim3(512), lds, st, p);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
+// SI_OK when launched, negative on error, 1 when the shape is not covered (the caller launches the two convolutions).
+// Shape limits (k odd in 3..11, (k - 1) * dil <= 50, 32-bit in-clip byte offsets) are checked by si_launch_respair.
+int si_launch_respair_wide(si_ctx* ctx, int C, const ResPairParams& p, hipStream_t st) {
+    if (C == 128) return respair_wide_launch<128, 256, 4, 2, 128>(ctx, p, st);
+    if (C == 256) return respair_wide_launch<256, 128, 2, 4, 64>(ctx, p, st);
+    return 1;
+}

@@ -91,8 +91,9 @@ def _masked_wave_span(c, margin_frames=16):
 
 # measured on MI355X (round 2): feats relative rms error and label agreement of the bf16 encoder against the reference's
 # fp32 goldens; the asserted bounds are 2x the measured error / the measured agreement floor
-BF16_FEAT_REL = {"base_4s": 2e-2, "large_4s": 2e-2, "tiny_layer": 2e-2, "tiny_group": 2e-2}
-BF16_AGREE_FLOOR = {"base_4s": 0.8, "large_4s": 0.8, "tiny_layer": 0.8, "tiny_group": 0.8}
+# (measured: feats rel 9.0e-3 / 6.8e-3 / 7.4e-3 / 9.3e-3; agreement 10/10, 20/20, 10/10, 28/30)
+BF16_FEAT_REL = {"base_4s": 2e-2, "large_4s": 1.5e-2, "tiny_layer": 1.5e-2, "tiny_group": 2e-2}
+BF16_AGREE_FLOOR = {"base_4s": 0.9, "large_4s": 0.9, "tiny_layer": 0.9, "tiny_group": 0.85}
 
 
 def _check_wave(name, c, out, gate):
@@ -113,6 +114,13 @@ def _check_wave(name, c, out, gate):
         err, where = max(rms(out["wave"][:, :2048], z["wave_head"]), rms(out["wave"][:, -2048:], z["wave_tail"])), "head + tail"
     print(f"{name}: label agreement {agree:.2f}, waveform rms error {err:.3e} ({where}; signal rms {float(z['wave_rms']):.3f})")
     assert err <= gate, (name, err, where)
+    if agree < 1.0:
+        # the samples a flipped codeword reaches: the oracle's vocoder on the mel THIS run spliced must give this waveform
+        from oracle import ref_cpu as R
+        ref2 = R.generator_forward(c["gsd"], c["varch"], R.extend_mel(out["mel"]))[:, 0, :]
+        err2 = rms(out["wave"], ref2)
+        print(f"{name}: vs the oracle's vocoder on the spliced mel of this run: waveform rms error {err2:.3e}")
+        assert err2 <= gate, (name, err2)
     return agree, err
 
 

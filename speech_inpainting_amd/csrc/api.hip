@@ -77,6 +77,9 @@ struct si_ctx {
     size_t prof_used = 0;
     int prof_open = -1;
     std::map<const void*, size_t> dyn_lds;   // per kernel: dynamic-LDS limit already raised on this context's device
+    // arithmetic-path options, read from the environment when the context is created (all default to 1)
+    bool opt_voc_opready = true, opt_voc_res16 = true, opt_enc_opready = true, opt_att_bf16 = true;
+    int opt_voc_fuse = 1;                    // 0: never, 1: every covered width, otherwise a mask of the channel counts to fuse (32 | 64 | 128 | 256)
     // constant tables of the mel front-end (built on first use): DFT matrix [Npad][n_fft] = rows cos | -sin, periodic
     // Hann window, transposed Slaney mel basis with the non-zero bin span of every band
     char* fe_dev = nullptr;
@@ -581,6 +584,12 @@ int si_create(si_ctx** out, int device_id, const si_model_desc* desc) {
     si_ctx* ctx = new si_ctx();
     ctx->device = device_id;
     ctx->d = *desc;
+    auto env_flag = [](const char* name) { const char* v = getenv(name); return v ? atoi(v) != 0 : true; };
+    ctx->opt_voc_opready = env_flag("SI_VOC_OPREADY");
+    ctx->opt_voc_res16 = env_flag("SI_VOC_RES16");
+    ctx->opt_voc_fuse = getenv("SI_VOC_FUSE") ? atoi(getenv("SI_VOC_FUSE")) : 1;
+    ctx->opt_enc_opready = env_flag("SI_ENC_OPREADY");
+    ctx->opt_att_bf16 = env_flag("SI_ATT_BF16");
     plan_layout(ctx);
     *out = ctx;
     return SI_OK;
@@ -665,8 +674,7 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     double* partials = reinterpret_cast<double*>(W.bytes(si_conv0_partials_bytes(B, N)));
     float* affine = W.floats((size_t)B * d.conv_dim[0] * 2);
     float* cbuf[2] = {W.floats((size_t)B * cmax), W.floats((size_t)B * cmax)};
-    static const int enc_opr_env0 = getenv("SI_ENC_OPREADY") ? atoi(getenv("SI_ENC_OPREADY")) : 1;
-    const bool c16 = enc_opr_env0 && d.encoder_math == SI_MATH_BF16 && !d.feat_norm_layer && d.num_conv >= 2;
+    const bool c16 = ctx->opt_enc_opready && d.encoder_math == SI_MATH_BF16 && !d.feat_norm_layer && d.num_conv >= 2;
     unsigned short* cb16[2] = {reinterpret_cast<unsigned short*>(cbuf[0]), reinterpret_cast<unsigned short*>(cbuf[1])};   // same storage, bf16 view
     float* lnf = W.floats(BT * CF);
     float* h = W.floats(BT * H);
@@ -678,8 +686,7 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     // also / only write bf16(x) -- the rounding the consuming GEMM would apply while staging -- so the four GEMMs of a
     // layer load 2-byte operands (their dominant traffic: M = B*T rows re-read by every N-tile) and skip the
     // conversion.  Bit-identical to converting in the consumer.  SI_ENC_OPREADY=0 restores fp32 inputs.
-    static const int enc_opr_env = getenv("SI_ENC_OPREADY") ? atoi(getenv("SI_ENC_OPREADY")) : 1;
-    const bool e16 = enc_opr_env && d.encoder_math == SI_MATH_BF16;
+    const bool e16 = ctx->opt_enc_opready && d.encoder_math == SI_MATH_BF16;
     unsigned short* lnf16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * CF * 2)) : nullptr;
     unsigned short* h16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * H * 2)) : nullptr;
     unsigned short* att16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * H * 2)) : nullptr;
@@ -751,7 +758,7 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
         const LayerW& Wl = L.layers[l];
         if (!d.stable_layer_norm) {       // post-LN (modeling_hubert.py:371-404); h16 = bf16(h) when e16
             if ((rc = linear(ctx, Wl.qkv, h, qkv, BT, SI_ACT_NONE, nullptr, st, h16))) return rc;
-            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16))) return rc;
+            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16))) return rc;
             if ((rc = linear(ctx, Wl.out, att, h2, BT, SI_ACT_NONE, h, st, att16))) return rc;
             if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h, BT, H, eps, 0, st, h16))) return rc;
             if ((rc = linear(ctx, Wl.ffn1, h, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16))) return rc;
@@ -760,7 +767,7 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
         } else {                          // pre-LN "stable" (modeling_hubert.py:504-547); residual adds are in place
             if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h2, BT, H, eps, 0, st, h16))) return rc;
             if ((rc = linear(ctx, Wl.qkv, h2, qkv, BT, SI_ACT_NONE, nullptr, st, h16))) return rc;
-            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16))) return rc;
+            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16))) return rc;
             if ((rc = linear(ctx, Wl.out, att, h, BT, SI_ACT_NONE, h, st, att16))) return rc;
             if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h2, BT, H, eps, 0, st, h16))) return rc;
             if ((rc = linear(ctx, Wl.ffn1, h2, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16))) return rc;
@@ -863,17 +870,14 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
     // what the next convolution would compute while staging -- so consumers copy 2-byte operands instead of loading
     // fp32 and converting; the ResBlock intermediate exists only in that form.  Same arithmetic, bit-identical output;
     // 20-40 % less HBM / L2 traffic on the convolution inputs.  SI_VOC_OPREADY=0 restores the fp32-input path.
-    static const int opready_env = getenv("SI_VOC_OPREADY") ? atoi(getenv("SI_VOC_OPREADY")) : 1;
-    const bool opr = opready_env && (d.vocoder_math == SI_MATH_BF16 || d.vocoder_math == SI_MATH_F16);
+    const bool opr = ctx->opt_voc_opready && (d.vocoder_math == SI_MATH_BF16 || d.vocoder_math == SI_MATH_F16);
     // fp16 activation stream (fp16 mode): activations live ONLY as raw fp16 -- the residual stream too -- and the
     // consumer applies its leaky-ReLU to the packed halves while staging: 10 instead of 16 bytes of HBM traffic per
     // element and conv pair (these stages run on the memory side in fp16).  The rounding it adds (fp16 after every
     // residual add) is small next to the operand rounding the mode already has: waveform RMS error 1.35e-4 vs 1.10e-4
     // (gate 1e-3).  SI_VOC_RES16=0 keeps the fp32 residual stream.
-    static const int res16_env = getenv("SI_VOC_RES16") ? atoi(getenv("SI_VOC_RES16")) : 1;
-    const bool r16 = opr && res16_env && d.vocoder_math == SI_MATH_F16;
-    static const int fuse_env = getenv("SI_VOC_FUSE") ? atoi(getenv("SI_VOC_FUSE")) : 1;
-    const bool fuse_pairs = fuse_env != 0;
+    const bool r16 = opr && ctx->opt_voc_res16 && d.vocoder_math == SI_MATH_F16;
+    const int fuse_mask = ctx->opt_voc_fuse == 1 ? ~0 : ctx->opt_voc_fuse;
     if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: vocoder workspace carve exceeded its own estimate");
     const int nk = d.num_rb;
     static const char* upn[] = {"ups0", "ups1", "ups2", "ups3", "ups4", "ups5", "ups6", "ups7"};
@@ -925,7 +929,7 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                 for (int n = 0; n < d.num_dil; ++n) {
                     const int dl = d.rb_dilations[j][n];
                     const bool last_n = (n == d.num_dil - 1);
-                    if (r16 && fuse_pairs) {
+                    if (r16 && (fuse_mask & cout)) {
                         // narrow stages: conv pair as one kernel, the intermediate stays in LDS (respair.hip)
                         const TapGemmParams w1 = gemm_params(ctx, R.c1[n]), w2 = gemm_params(ctx, R.c2[n]);
                         unsigned short* yn16 = last_n ? xs16 : h16[4 + (n & 1)];

@@ -97,8 +97,9 @@ int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const flo
 
 // softmax(q k^T / sqrt(64)) v for head_dim 64; qkv (B, T, 3H) packed [q | k | v]; out (B, T, H)
 // out16 (optional): write the result as bf16 there INSTEAD of fp32 into out
+// bf16_products: with out16 given, run both products on bf16 MFMA (fp32 softmax); false keeps the exact-fp32 kernel
 int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st,
-                        unsigned short* out16 = nullptr);
+                        unsigned short* out16 = nullptr, bool bf16_products = true);
 
 // cosine arg-max against centred centroids + splice of the raw centroid into mel (A10..A13)
 int si_launch_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,

@@ -571,12 +571,11 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __rest
 }
 
 int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st,
-                        unsigned short* out16) {
+                        unsigned short* out16, bool att_bf16) {
     if (heads <= 0 || H != heads * 64) return si_fail(ctx, SI_EINVAL, "attention kernel needs head_dim 64 (H=%d heads=%d)", H, heads);
     if (B <= 0 || T <= 0) return SI_OK;
     dim3 grid((T + 127) / 128, B * heads);
-    // bf16 encoder mode (out16 given): the bf16-MFMA form; SI_ATT_BF16=0 keeps the exact-fp32 MFMA kernel there too
-    static const int att_bf16 = getenv("SI_ATT_BF16") ? atoi(getenv("SI_ATT_BF16")) : 1;
+    // bf16 encoder mode (out16 given): the bf16-MFMA form; SI_ATT_BF16=0 at context creation keeps the exact-fp32 kernel
     si_prof_begin(ctx, (out16 && att_bf16) ? "attention_bf16" : "attention_f32", 4.0 * B * (double)T * T * H, 16.0 * B * T * H, st);   // 2*T^2*H MACs
     if (out16 && att_bf16) hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, st, qkv, out16, T, H, heads);
     else hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, qkv, out, out16, T, H, heads);

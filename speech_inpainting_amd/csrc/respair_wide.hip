@@ -17,45 +17,48 @@
 // Weight slabs ([C n][BKW ci] of one tap: 32 KB) stream L2 -> registers -> LDS through a double buffer, one workgroup
 // barrier per slab; a slab feeds 32 (C = 128) / 16 (C = 256) MFMAs per wave, against 8 per barrier in the tap-GEMM.
 //
-// MFMA orientation: D^T = W * Y^T (v_mfma_f32_32x32x16_f16 with the WEIGHT rows as the A operand): a lane then holds one
-// time row (column l&31) and, in registers 4g..4g+3, four CONSECUTIVE channels -- so the intermediate is written to LDS
-// with 8-byte stores and the output image with 16-byte stores, no shuffles.
+// MFMA: v_mfma_f32_16x16x32_f16, 4 x 4 tiles per 64 x 64 wave tile.  Under a dense MFMA stream the chip holds ~1.8 GHz on
+// this shape against ~1.45 GHz on 32x32x16 (tools/ubench/mfma_rate.hip: 1.82 vs 1.37-1.48 PFLOP/s sustained, LDS-fed), at
+// the same LDS traffic per flop.  Orientation: D^T = W * Y^T (the WEIGHT rows are the A operand): a lane then holds one
+// time row (column l & 15) and, in its 4 accumulator registers, four CONSECUTIVE channels -- so the intermediate is
+// written to LDS with 8-byte stores and the output image with 16-byte stores, no shuffles.
 //
-// LDS images are unpadded; 16-byte chunk c of row r lives at chunk c ^ f(r) (f = r & 15 for rows >= 256 bytes,
-// (r >> 1) & 7 for 128-byte rows), which spreads the 16 rows of a ds_read_b128 lane group over all 16 four-bank slots.
-// The XOR costs one VALU op per fragment read: pre = row base | ((f(r) ^ lane half) << 4) per (fragment row, tap), then
-// address = pre ^ (k-step * 32).
+// LDS images are unpadded; 16-byte chunk c of row r lives at chunk c ^ f(r) (swz16 below).  The XOR costs one VALU op per
+// fragment read: pre = row base | ((f(r) ^ k group) << 4) per (fragment row, tap), then address = pre ^ (k-step * 64).
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
 #include "common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+// (chunk XOR term of a row) << 4.  The 16x16x32 operand read of a ds_read_b128 lane group is 8 rows x chunk c and 8 other
+// rows x chunk c ^ 1 (lane l: row l & 15, k group l >> 4), so the term leaves chunk bit 0 alone -- the two halves of a group
+// can then never meet -- and spreads 8 consecutive rows over the 8 slot pairs: conflict-free for ANY first row (a tap is
+// an arbitrary row offset).
 template <int ROWB>
-__device__ __forceinline__ int swz16(int row) {                        // (chunk XOR term of a row) << 4
-    if constexpr (ROWB >= 256) return (row & 15) << 4;
-    else return ((row >> 1) & 7) << 4;                                // 128-byte rows: two rows per 256-byte bank period
+__device__ __forceinline__ int swz16(int row) {
+    if constexpr (ROWB >= 256) return (row & 7) << 5;
+    else return ((row >> 1) & 3) << 5;                                // 128-byte rows: two rows per 256-byte bank period
 }
 
 constexpr int RPW_HALO = 50;                                          // (k - 1) * dil <= 50: k = 11, dil = 5
 
 template <int C, int R1, int WARPS_M, int WARPS_N, int BKW>
-__global__ __launch_bounds__(512, 2) void respair_wide_kernel(const ResPairParams p) {
-    static_assert(WARPS_M * WARPS_N == 8 && R1 == WARPS_M * 64 && C == WARPS_N * 64, "8 waves, 64 x 64 wave tiles");
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel(const ResPairParams p) {
+    static_assert((WARPS_M * WARPS_N == 8 || WARPS_M * WARPS_N == 4) && R1 == WARPS_M * 64 && C == WARPS_N * 64, "64 x 64 wave tiles");
     static_assert(BKW == 128 || BKW == 64, "weight-slab depth");
-    constexpr int NT = 512;
+    constexpr int NT = 64 * WARPS_M * WARPS_N;                         // 512: one workgroup per CU; 256: two (two waves per SIMD either way)
     constexpr int ROWBY = C * 2;                                       // bytes per activation / intermediate row
     constexpr int ROWBW = BKW * 2;                                     // bytes per weight-slab row
     constexpr int ROWBO = C * 4;                                       // bytes per fp32 output-image row
     constexpr int CPRY = C / 8, CPRW = BKW / 8;                        // 16-byte chunks per row
     constexpr int NCH = C / BKW;                                       // weight slabs per tap
-    constexpr int KS = BKW / 16;                                       // MFMA k-steps per slab
+    constexpr int KS = BKW / 32;                                       // MFMA k-steps (K = 32) per slab
     constexpr int YBYTES = (R1 + RPW_HALO) * ROWBY;
     constexpr int WBYTES = C * ROWBW;
     constexpr int WSLOTS = C * CPRW / NT;
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(512, 2) void respair_wide_kernel(const ResPairParam
     float* const Bs = reinterpret_cast<float*>(smem + YBYTES + 2 * WBYTES);   // [2][C] fp32: b1, b2 (outside the output image)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
+    const int r16 = lane & 15, kg = lane >> 4;                        // operand row / k group of this lane (also: C column / row group)
     const int wm0 = (wave / WARPS_N) * 64, wn0 = (wave % WARPS_N) * 64;
     const int k = p.k, d = p.dil;
     const int p1 = d * (k - 1) / 2, p2 = (k - 1) / 2;
@@ -104,12 +107,13 @@ __global__ __launch_bounds__(512, 2) void respair_wide_kernel(const ResPairParam
             rw[i] = __builtin_amdgcn_raw_buffer_load_b128(second ? w2rsrc : w1rsrc, (n * C + 8 * wc) * 2, soff, 0);
         }
     };
+    auto storeW1 = [&](char* dst, int i) {
+        const int n = wr0 + i * WRPP;
+        *reinterpret_cast<u32x4*>(dst + n * ROWBW + ((wc << 4) ^ swz16<ROWBW>(n))) = rw[i];
+    };
     auto storeW = [&](char* dst) {
 #pragma unroll
-        for (int i = 0; i < WSLOTS; ++i) {
-            const int n = wr0 + i * WRPP;
-            *reinterpret_cast<u32x4*>(dst + n * ROWBW + ((wc << 4) ^ swz16<ROWBW>(n))) = rw[i];
-        }
+        for (int i = 0; i < WSLOTS; ++i) storeW1(dst, i);
     };
 
     issueW(0);
@@ -125,11 +129,11 @@ __global__ __launch_bounds__(512, 2) void respair_wide_kernel(const ResPairParam
         for (int i = 0; i < YSLOTS; ++i)
             ry[i] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, ((y_row0 + yr0 + i * YRPP) * C + 8 * yc) * 2, 0, 0);
         storeW(Ws);                                                    // slab 0 has landed; the tile is still in flight
-        issueW(NS > 1 ? 1 : 0);
+        issueW(1);                                                     // stays in registers until slab 0 starts (NS >= 6)
 #pragma unroll
         for (int i = 0; i < YSLOTS; ++i) {
             const int r = yr0 + i * YRPP;
-            if (r < R0) {
+            if ((i + 1) * YRPP <= R1 || r < R0) {                       // rows < R1 always exist: no branch around their loads
                 f16x8 h = __builtin_bit_cast(f16x8, ry[i]);
                 const f16x8 hs = h * (_Float16)0.1f;
 #pragma unroll
@@ -140,113 +144,137 @@ __global__ __launch_bounds__(512, 2) void respair_wide_kernel(const ResPairParam
     }
     __syncthreads();
 
-    f32x16 acc[2][2];                                                  // [time tile i][channel tile j], transposed tiles
+    f32x4 acc[4][4];                                                   // [time tile i][channel tile j], transposed 16 x 16 tiles
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     zero_acc();
-    int preW[2];
+    int preW[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = wn0 + 32 * j + l31;
-        preW[j] = n * ROWBW + (swz16<ROWBW>(n) ^ (half << 4));
+    for (int j = 0; j < 4; ++j) {
+        const int n = wn0 + 16 * j + r16;
+        preW[j] = n * ROWBW + (swz16<ROWBW>(n) ^ (kg << 4));
     }
-    // one slab: acc^T += W[slab] * A[rows + roff][chunk columns]^T
-    auto compute = [&](int roff, int cb16, const char* Wc) {
-        int preY[2];
+    // one slab: acc^T += W[slab] * A[rows + roff][chunk columns]^T.  Fragments are double-buffered in registers: the
+    // reads of k-step ks + 1 are issued before the MFMAs of k-step ks, so an MFMA never waits on a read issued just
+    // ahead of it.  `hook(ks)` runs behind the MFMAs of k-step ks: the weight-slab stores and the next slab's loads are
+    // spread over the k-steps there instead of forming a 32 KB ds_write burst at the slab boundary.
+    auto compute = [&](int roff, int cb16, const char* Wc, auto&& hook) {
+        int preY[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = wm0 + 32 * i + l31 + roff;
-            preY[i] = r * ROWBY + (((r & 15) ^ half) << 4);
+        for (int i = 0; i < 4; ++i) {
+            const int r = wm0 + 16 * i + r16 + roff;
+            preY[i] = r * ROWBY + (swz16<ROWBY>(r) ^ (kg << 4));
         }
+        auto load = [&](f16x8 (&y)[4], f16x8 (&w)[4], int ks) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            f16x8 y[2], w[2];
+            for (int i = 0; i < 4; ++i) y[i] = *reinterpret_cast<const f16x8*>(Ys + (preY[i] ^ (cb16 + ks * 64)));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) y[i] = *reinterpret_cast<const f16x8*>(Ys + (preY[i] ^ (cb16 + ks * 32)));
+            for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const f16x8*>(Wc + (preW[j] ^ (ks * 64)));
+        };
+        auto mma = [&](const f16x8 (&y)[4], const f16x8 (&w)[4]) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) w[j] = *reinterpret_cast<const f16x8*>(Wc + (preW[j] ^ (ks * 32)));
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], y[i], acc[i][j], 0, 0, 0);
+        };
+        // sched_barrier(0): left alone, the scheduler folds the two register sets back into one and puts each read right
+        // behind the MFMA that frees its register, a few cycles ahead of its use
+        f16x8 ya[4], wa[4], yb[4], wb[4];
+        load(ya, wa, 0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[j], y[i], acc[i][j], 0, 0, 0);
+        for (int ks = 0; ks < KS; ks += 2) {
+            load(yb, wb, ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            mma(ya, wa);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            hook(ks);
+            if (ks + 2 < KS) load(ya, wa, ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            mma(yb, wb);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            hook(ks + 1);
         }
     };
 
     int tap = 0, ch = 0;                                               // of slab s within its convolution
-    for (int s = 0; s < NS; ++s) {
+    for (int s = 0; s < NS - 1; ++s) {
         const bool second = s >= NS1;
-        compute(second ? tap : tap * d, ch * (BKW * 2), Ws + (s & 1) * WBYTES);
+        char* const Wn = Ws + ((s + 1) & 1) * WBYTES;
+        static_assert(WSLOTS % KS == 0, "the slab's stores are spread evenly over its k-steps");
+        compute(second ? tap : tap * d, ch * (BKW * 2), Ws + (s & 1) * WBYTES, [&](int ks) {
+#pragma unroll
+            for (int i = 0; i < WSLOTS / KS; ++i) storeW1(Wn, ks * (WSLOTS / KS) + i);
+            // unconditional (clamped to the last slab): a conditional load drains vmcnt at the join
+            if (ks == KS - 1) issueW(s + 2 < NS ? s + 2 : NS - 1);
+        });
         if (s == NS1 - 1) {
             __syncthreads();                                           // every wave has finished reading the activation tile
             // ---- phase-1 epilogue: bias, leaky-ReLU, zero outside the clip, fp16, over the activation tile
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = wm0 + 32 * i + l31;
+            for (int i = 0; i < 4; ++i) {
+                const int m = wm0 + 16 * i + r16;
                 const int grow = t_row0 + m;
-                const bool inside = grow >= 0 && grow < p.L;
+                const float inside = (grow >= 0 && grow < p.L) ? 1.f : 0.f;    // as a factor: no branch per element
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 4; ++j) {
+                    const int n = wn0 + 16 * j + 4 * kg;               // this lane's four consecutive channels
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(Bs + n);
+                    f16x4 hv;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = wn0 + 32 * j + 8 * g + 4 * half;
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(Bs + n);
-                        f16x4 hv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = acc[i][j][4 * g + e] + bv[e];
-                            v = v > 0.f ? v : 0.1f * v;
-                            v = inside ? __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f) : 0.f;
-                            hv[e] = (_Float16)v;
-                        }
-                        *reinterpret_cast<f16x4*>(Ys + m * ROWBY + ((((n >> 3) ^ (m & 15)) << 4) + 8 * half)) = hv;
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][e] + bv[e];
+                        v = v > 0.f ? v : 0.1f * v;
+                        v = __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f) * inside;
+                        hv[e] = (_Float16)v;
                     }
+                    *reinterpret_cast<f16x4*>(Ys + m * ROWBY + ((((n >> 3) << 4) ^ swz16<ROWBY>(m)) + 8 * (kg & 1))) = hv;
+                }
             }
             zero_acc();
         }
         if (++ch == NCH) { ch = 0; if (++tap == k) tap = 0; }
-        if (s + 1 < NS) {
-            storeW(Ws + ((s + 1) & 1) * WBYTES);                       // slab s + 1, in flight since the previous iteration
-            issueW(s + 2 < NS ? s + 2 : NS - 1);                       // unconditional: a conditional load drains vmcnt at the join
-            __syncthreads();
-        }
+        __syncthreads();                                               // slab s + 1 (and, after phase 1, the intermediate) is visible
     }
+    // ---- last slab (tap k - 1, last chunk of conv 2).  The residual / accumulate rows of the output pass are requested
+    //      first, so that they arrive under its MFMAs: a lane owns 8 consecutive channels of OPASS output rows.
+    constexpr int ORPP = NT / CPRY;                                    // output rows per pass
+    constexpr int OPASS = R1 / ORPP;
+    const int c8 = tid % CPRY, or0 = tid / CPRY;
+    u32x4 res[OPASS], prev[OPASS];
+    int goff[OPASS];
+#pragma unroll
+    for (int it = 0; it < OPASS; ++it) {
+        const int o = or0 + it * ORPP;
+        const int grow = m0 + o;
+        goff[it] = (o < BMo && grow < p.L) ? (grow * C + 8 * c8) * 2 : (int)0x80000000;
+        res[it] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, goff[it], 0, 0);
+        if (p.accumulate) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, goff[it], 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    compute(tap, ch * (BKW * 2), Ws + ((NS - 1) & 1) * WBYTES, [](int) {});
+    __syncthreads();                                                   // every wave is done with the operand tiles
 
     // ---- final epilogue: accumulators -> fp32 image of the output tile in LDS -> row-contiguous residual add + store
-    __syncthreads();                                                   // every wave is done with the operand tiles
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = wm0 + 32 * i + l31;
+    for (int i = 0; i < 4; ++i) {
+        const int m = wm0 + 16 * i + r16;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = ((wn0 + 32 * j) >> 2) + 2 * g + half;   // 16-byte chunk (4 channels) of the output row
-                const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                *reinterpret_cast<f32x4*>(smem + m * ROWBO + ((co ^ (m & 15)) << 4)) = v;
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int co = ((wn0 + 16 * j) >> 2) + kg;                 // 16-byte chunk (4 channels) of the output row
+            *reinterpret_cast<f32x4*>(smem + m * ROWBO + ((co ^ (m & 15)) << 4)) = acc[i][j];
+        }
     }
     __syncthreads();
     {
-        constexpr int ORPP = NT / CPRY;                                // output rows per pass: a lane owns 8 channels of a row
-        constexpr int OPASS = R1 / ORPP;
-        const int c8 = tid % CPRY, or0 = tid / CPRY;
         const f32x4 b2a = *reinterpret_cast<const f32x4*>(Bs + C + 8 * c8), b2b = *reinterpret_cast<const f32x4*>(Bs + C + 8 * c8 + 4);
-        u32x4 res[OPASS], prev[OPASS];
-        int goff[OPASS];
-#pragma unroll
-        for (int it = 0; it < OPASS; ++it) {
-            const int o = or0 + it * ORPP;
-            const int grow = m0 + o;
-            goff[it] = (o < BMo && grow < p.L) ? (grow * C + 8 * c8) * 2 : (int)0x80000000;
-            res[it] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, goff[it], 0, 0);
-            if (p.accumulate) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, goff[it], 0, 0);
-        }
 #pragma unroll
         for (int it = 0; it < OPASS; ++it) {
             const int o = or0 + it * ORPP;
@@ -270,7 +298,8 @@ __global__ __launch_bounds__(512, 2) void respair_wide_kernel(const ResPairParam
 }
 
 template <int C, int R1, int WARPS_M, int WARPS_N, int BKW>
-static int respair_wide_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t st) {
+static int respair_wide_launch(si_ctx* ctx, const ResPairParams& p0, hipStream_t st) {
+    const ResPairParams& p = p0;
     const int BMo = R1 - (p.k - 1);
     const size_t lds = (size_t)(R1 + RPW_HALO) * C * 2 + 2 * (size_t)C * BKW * 2 + 2 * (size_t)C * 4;
     auto kern = respair_wide_kernel<C, R1, WARPS_M, WARPS_N, BKW>;
@@ -279,7 +308,7 @@ static int respair_wide_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t 
     snprintf(name, sizeof(name), "respair_f16_c%d", C);
     const double elems = (double)p.B * p.L * C;
     si_prof_begin(ctx, name, 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 2.0 * 2.0 * p.k * C * C, st);
-    hipLaunchKernelGGL(kern, dim3((p.L + BMo - 1) / BMo, p.B), dim3(512), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((p.L + BMo - 1) / BMo, p.B), dim3(64 * WARPS_M * WARPS_N), lds, st, p);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
@@ -288,6 +317,10 @@ static int respair_wide_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t 
 // SI_OK when launched, negative on error, 1 when the shape is not covered (the caller launches the two convolutions).
 // Shape limits (k odd in 3..11, (k - 1) * dil <= 50, 32-bit in-clip byte offsets) are checked by si_launch_respair.
 int si_launch_respair_wide(si_ctx* ctx, int C, const ResPairParams& p, hipStream_t st) {
+    // C = 128: one 8-wave workgroup per CU on 256 rows with whole-tap weight slabs.  (Measured against two 4-wave
+    // workgroups per CU on 128 rows / half-tap slabs, which overlap one workgroup's tile load and output pass with the
+    // other's MFMAs: 206 / 368 / 515 us per launch for k = 3 / 7 / 11 against 204 / 370 / 576 -- the second form streams
+    // every weight slab twice as often per flop, and weight staging is the loop's largest overhead.)
     if (C == 128) return respair_wide_launch<128, 256, 4, 2, 128>(ctx, p, st);
     if (C == 256) return respair_wide_launch<256, 128, 2, 4, 64>(ctx, p, st);
     return 1;

@@ -92,6 +92,8 @@ int si_launch_conv_post(si_ctx* ctx, const float* x, const float* w, const float
     if (C % 4 != 0) return si_fail(ctx, SI_EINVAL, "conv_post: C=%d must be a multiple of 4", C);
     if (B <= 0 || L <= 0) return SI_OK;
     const size_t lds = ((size_t)(256 + k - 1) * (C + 1) + (size_t)k * C) * sizeof(float);
+    if (lds > 160 * 1024) return si_fail(ctx, SI_EINVAL, "conv_post: %d channels x %d taps need %zu bytes of LDS (> 160 KiB)", C, k, lds);
+    if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(conv_post_kernel), lds)) return rc;
     dim3 grid((L + 255) / 256, B);
     si_prof_begin(ctx, "conv_post", 2.0 * B * L * (double)C * k, (double)B * L * ((x16 ? 2.0 : 4.0) * C + 4.0), st);
     hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), lds, st, x, x16, w, bias, L, C, k, wav);

@@ -22,6 +22,9 @@ def family(kernel_name: str) -> str:
     m = re.search(r"tapgemm_kernel<(\d), (\d+), (\d+), (\d), (\d), (\d+)", kernel_name)
     if m:      # bench.py's family name: tapgemm_<math>_<BM>x<BN>[w8]
         return f"tapgemm_{MATH[m.group(1)]}_{m.group(2)}x{m.group(3)}" + ("w8" if int(m.group(4)) * int(m.group(5)) == 8 else "")
+    m = re.search(r"respair(?:_wide)?_kernel<(\d+)", kernel_name)
+    if m:      # bench.py's family name: respair_f16_c<C>
+        return f"respair_f16_c{m.group(1)}"
     return re.sub(r"_kernel.*|\(.*", "", kernel_name).replace("void ", "")
 
 

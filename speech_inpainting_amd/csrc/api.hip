@@ -78,7 +78,7 @@ struct si_ctx {
     int prof_open = -1;
     std::map<const void*, size_t> dyn_lds;   // per kernel: dynamic-LDS limit already raised on this context's device
     // arithmetic-path options, read from the environment when the context is created (all default to 1)
-    bool opt_voc_opready = true, opt_voc_res16 = true, opt_enc_opready = true, opt_att_bf16 = true;
+    bool opt_voc_opready = true, opt_voc_res16 = true, opt_enc_opready = true, opt_att_bf16 = true, opt_enc_lingemm = true;
     int opt_voc_fuse = 1;                    // 0: never, 1: every covered width, otherwise a mask of the channel counts to fuse (32 | 64 | 128 | 256)
     // constant tables of the mel front-end (built on first use): DFT matrix [Npad][n_fft] = rows cos | -sin, periodic
     // Hann window, transposed Slaney mel basis with the non-zero bin span of every band
@@ -559,6 +559,7 @@ int linear(si_ctx* ctx, const GemmW& G, const float* x, float* y, long rows, int
     p.x = x16 ? nullptr : x; p.x16 = x16; p.out = y; p.out16 = y16; p.res = res; p.act = act;
     p.nseg = 1; p.Lin = (int)rows; p.M = (int)rows; p.ldx = G.Cin; p.x_seg_stride = 0;
     p.ldo = G.N; p.o_seg_stride = 0; p.ooff = 0; p.olimit = rows * G.N;
+    p.lingemm = ctx->opt_enc_lingemm;
     return si_launch_tapgemm(ctx, G.math, p, st);
 }
 
@@ -590,6 +591,7 @@ int si_create(si_ctx** out, int device_id, const si_model_desc* desc) {
     ctx->opt_voc_fuse = getenv("SI_VOC_FUSE") ? atoi(getenv("SI_VOC_FUSE")) : 1;
     ctx->opt_enc_opready = env_flag("SI_ENC_OPREADY");
     ctx->opt_att_bf16 = env_flag("SI_ATT_BF16");
+    ctx->opt_enc_lingemm = env_flag("SI_ENC_LINGEMM");
     plan_layout(ctx);
     *out = ctx;
     return SI_OK;
@@ -721,6 +723,7 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
         p.stride = d.conv_stride[i]; p.ldo = d.conv_dim[i]; p.o_seg_stride = (long)e.L[i + 1] * d.conv_dim[i];
         p.olimit = p.o_seg_stride;
         p.act = d.feat_norm_layer ? SI_ACT_NONE : SI_ACT_GELU;
+        p.lingemm = ctx->opt_enc_lingemm;
         if ((rc = si_launch_tapgemm(ctx, c.g.math, p, st))) return rc;
         cur ^= 1;
         if (d.feat_norm_layer &&

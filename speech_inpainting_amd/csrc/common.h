@@ -60,6 +60,7 @@ struct TapGemmParams {
     int accumulate;        // out = v + out
     double algo_macs;      // algorithmic multiply-accumulates of the layer (0: derive from the GEMM shape)
     int wide_epilogue;     // set by the launcher: row-contiguous 16-byte epilogue through an LDS transpose
+    int lingemm;           // caller allows the dedicated bf16 GEMM kernel (lingemm.hip) when the shape fits it
 };
 
 // N-tile width the launcher uses for a given N; the packer pads W rows to a multiple of it.
@@ -67,6 +68,22 @@ static inline int si_pick_bn(int N) { return N >= 128 ? 128 : (N > 32 ? 64 : 32)
 static inline int si_round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t st);
+
+// The encoder's bf16 GEMM (lingemm.hip): out[seg][m][n] = epi(sum_k A[seg][m][k] W[n][k] + bias[n]); A row m = K
+// consecutive bf16 at x16 + seg * x_seg_stride + m * lda (lda < K: overlapping rows = a strided convolution on
+// channels-last activations); W = ntaps blocks [N][Cin] (k = tap * Cin + ci).  Returns 1 when the shape is not covered.
+struct LinGemmParams {
+    const unsigned short* x16; int x_bytes;     // activations (bf16) and the size of their buffer in bytes
+    int lda; long x_seg_stride;                 // elements between consecutive A rows / segments
+    int nseg, M, K;
+    const unsigned short* w; int w_bytes;
+    int N, Cin, ntaps; long w_tap_stride;       // elements between tap blocks of W
+    const float* bias; const float* res;        // res: fp32, indexed like out
+    float* out; unsigned short* out16;          // fp32 and / or bf16 output
+    int ldo; long o_seg_stride;
+    int act;
+};
+int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // encoder kernels (encoder_kernels.hip)

@@ -1,0 +1,204 @@
+// lingemm.hip -- the encoder's bf16 GEMM (gfx950, wave64, v_mfma_f32_16x16x32_bf16).
+//
+//     out[seg][m][n] = epi( sum_k A[seg][m][k] * W[n][k] + bias[n] )        A row m = K consecutive bf16 at x16 + m * lda
+//
+// covers, on operand-ready bf16 activations (the bf16 encoder mode):
+//   * every Linear of the transformer (modeling_hubert.py:262-368: q/k/v fused, out-proj + residual, FFN1 + GELU, FFN2 +
+//     residual) and the feature projection (:216-231): lda = K;
+//   * the six strided feature-extractor convolutions (:106-124; k = 3 / 2, stride 2, no padding): on channels-last
+//     activations the k taps of output row m are the k * Cin CONSECUTIVE values starting at input row m * stride, so the
+//     convolution is this GEMM with overlapping A rows (lda = stride * Cin, K = k * Cin) and the tap-major weight blocks
+//     W[tap][n][ci] read as K chunks.
+// It replaces the generic tap-GEMM (tapgemm.hip: 128x128 tile, eight 32x64 waves, 32x32x16 MFMA, 16-byte row padding)
+// for these shapes: 64x64 wave tiles cut the LDS reads per MFMA by a third, the 16x16x32 MFMA shape holds a higher
+// clock under load (tools/ubench/mfma_rate.hip), a 64-deep K chunk feeds 32 MFMAs per wave between barriers instead of
+// 8, and the output goes through an LDS image so that every global access is a whole row segment.
+//
+// Structure (as respair_wide.hip): one 4-wave workgroup per 128 x 128 tile, two workgroups per CU.  K chunks of 64
+// stream global -> registers -> LDS through a double buffer with the stores spread behind the MFMA blocks; one barrier
+// per chunk.  Orientation D^T = W * A^T: a lane holds one output row (column l & 15) and four consecutive output
+// columns, so the fp32 output image is written with 16-byte stores.  LDS rows are 128 bytes, chunk c of row r lives at
+// chunk c ^ (((r >> 1) & 3) << 1): conflict-free for the 16x16x32 operand read (see respair_wide.hip).
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float lg_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+constexpr int LG_BM = 128, LG_BN = 128, LG_BK = 64, LG_NT = 256;
+constexpr int LG_ROWB = LG_BK * 2;                                     // 128-byte LDS rows
+constexpr int LG_TILE = LG_BM * LG_ROWB;                               // 16 KB per operand per buffer
+
+__device__ __forceinline__ int lg_swz(int row) { return ((row >> 1) & 3) << 5; }
+
+__global__ __launch_bounds__(LG_NT, 2) void lingemm_kernel(const LinGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][A 128 x 64 | W 128 x 64] bf16 = 64 KB; later the fp32 output image
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+
+    const int ntn = p.N / LG_BN;
+    const int mtiles = (p.M + LG_BM - 1) / LG_BM;
+    const int tile = blockIdx.x;
+    const int mt = tile / ntn;                                         // N tiles of one M tile are adjacent: they share A rows in L2
+    const int seg = mt / mtiles;
+    const int m0 = (mt - seg * mtiles) * LG_BM;
+    const int n0 = (tile - mt * ntn) * LG_BN;
+
+    // A rows through a descriptor over the whole activation buffer (reads past its end return zero; rows >= M of the last
+    // tile of a segment read the next segment's data or zero and only feed output rows that are never stored)
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.x16), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0, p.w_bytes, 0x00020000);
+    const int sc = tid & 7, sr0 = tid >> 3;                            // staging: 16-byte chunk sc of rows sr0 + 32 i
+    const int a_voff = (int)(((long)seg * p.x_seg_stride + (long)(m0 + sr0) * p.lda) * 2) + sc * 16;
+    const int a_step = p.lda * 2 * 32;
+    const int w_voff = ((n0 + sr0) * p.Cin) * 2 + sc * 16;
+    const int w_step = p.Cin * 2 * 32;
+    const int cpt = p.Cin / LG_BK;                                     // K chunks per tap block of the weights
+    // two register sets: chunk c + 1 (set (c + 1) & 1) is on its way to LDS while chunk c + 2 is still in flight -- one
+    // chunk of MFMAs (~0.5 us) does not cover an L2 round trip under load, two do
+    u32x4 ra[2][4], rw[2][4];
+    auto issue = [&](auto set, int c) {
+        constexpr int S = decltype(set)::value;
+        const int tap = c / cpt;
+        const int a_soff = __builtin_amdgcn_readfirstlane(c * LG_BK * 2);
+        const int w_soff = __builtin_amdgcn_readfirstlane((int)(((long)tap * p.w_tap_stride + (long)(c - tap * cpt) * LG_BK) * 2));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[S][i] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff + i * a_step, a_soff, 0);
+            rw[S][i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff + i * w_step, w_soff, 0);
+        }
+    };
+    const int s_off = sr0 * LG_ROWB + ((sc << 4) ^ lg_swz(sr0));       // rows sr0 + 32 i share the swizzle term of sr0
+    auto store1 = [&](auto set, char* buf, int i) {
+        constexpr int S = decltype(set)::value;
+        *reinterpret_cast<u32x4*>(buf + s_off + i * 32 * LG_ROWB) = ra[S][i];
+        *reinterpret_cast<u32x4*>(buf + LG_TILE + s_off + i * 32 * LG_ROWB) = rw[S][i];
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int preA[4], preW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wm0 + 16 * i + r16, n = wn0 + 16 * i + r16;
+        preA[i] = r * LG_ROWB + (lg_swz(r) ^ (kg << 4));
+        preW[i] = LG_TILE + n * LG_ROWB + (lg_swz(n) ^ (kg << 4));
+    }
+    auto load = [&](bf16x8 (&a)[4], bf16x8 (&w)[4], const char* buf, int ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(buf + (preA[i] ^ (ks * 64)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const bf16x8*>(buf + (preW[j] ^ (ks * 64)));
+    };
+    auto mma = [&](const bf16x8 (&a)[4], const bf16x8 (&w)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a[i], acc[i][j], 0, 0, 0);
+    };
+
+    const int nchunks = p.K / LG_BK;
+    const int last = nchunks - 1;
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    issue(S0{}, 0);
+    issue(S1{}, last < 1 ? last : 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store1(S0{}, smem, i);                 // chunk 0; chunk 1 stays in set 1
+    issue(S0{}, last < 2 ? last : 2);
+    __syncthreads();
+    // Iteration c reads chunk c from LDS buffer c & 1, writes chunk c + 1 (register set (c + 1) & 1, requested two
+    // iterations ago) to the other buffer behind the MFMA blocks and requests chunk c + 3 into that same set; loads are
+    // unconditional (clamped to the last chunk): a conditional load drains vmcnt at the join.
+    auto step = [&](auto land, int c) {
+        const char* buf = smem + (c & 1) * (2 * LG_TILE);
+        char* nxt = smem + ((c + 1) & 1) * (2 * LG_TILE);
+        bf16x8 aa[4], wa[4], ab[4], wb[4];
+        load(aa, wa, buf, 0);
+        load(ab, wb, buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma(aa, wa);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        store1(land, nxt, 0);                                          // (after the last chunk: a dead buffer)
+        store1(land, nxt, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma(ab, wb);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        store1(land, nxt, 2);
+        store1(land, nxt, 3);
+        issue(land, c + 3 < nchunks ? c + 3 : last);
+        __syncthreads();
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        step(S1{}, c);
+        if (c + 1 < nchunks) step(S0{}, c + 1);
+    }
+
+    // ---- epilogue: accumulators -> fp32 image of the tile in LDS -> bias / GELU / residual -> row-contiguous stores
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = wm0 + 16 * i + r16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = ((wn0 + 16 * j) >> 2) + kg;                 // 16-byte chunk (4 columns) of the 512-byte image row
+            *reinterpret_cast<f32x4*>(smem + m * 512 + ((co ^ (m & 15)) << 4)) = acc[i][j];
+        }
+    }
+    __syncthreads();
+    const int c4 = tid & 31, er0 = tid >> 5;                           // a lane owns 4 consecutive columns of rows er0 + 8 it
+    const int n = n0 + 4 * c4;
+    const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const long obase = (long)seg * p.o_seg_stride;
+    const bool gelu = p.act == SI_ACT_GELU;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int r = er0 + 8 * it;
+        const int m = m0 + r;
+        if (m >= p.M) break;                                           // rows ascend with `it`
+        const long o = obase + (long)m * p.ldo + n;
+        f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * 512 + ((c4 ^ (r & 15)) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e] + bv[e];
+            if (gelu) x = lg_gelu(x);
+            v[e] = x;
+        }
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
+        if (p.out) *reinterpret_cast<f32x4*>(p.out + o) = v;
+        if (p.out16) *reinterpret_cast<bf16x4*>(p.out16 + o) = __builtin_convertvector(v, bf16x4);
+    }
+}
+
+// SI_OK when launched, negative on error, 1 when the shape is not covered (the caller uses the tap-GEMM).
+int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
+    if (p.N % LG_BN || p.Cin % LG_BK || p.K % LG_BK || p.K != p.ntaps * p.Cin || p.ldo % 4 || p.lda % 8 || p.M <= 0 || p.nseg <= 0) return 1;
+    if (p.x_bytes <= 0 || p.w_bytes <= 0 || (long)p.nseg * p.x_seg_stride * 2 + (long)(p.M + LG_BM) * p.lda * 2 >= (1L << 31)) return 1;
+    if (!p.out && !p.out16) return si_fail(ctx, SI_EINVAL, "lingemm: no output");
+    const size_t lds = 4 * (size_t)LG_TILE;
+    if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(lingemm_kernel), lds)) return rc;
+    const int mtiles = (p.M + LG_BM - 1) / LG_BM;
+    const double macs = (double)p.nseg * p.M * p.N * (double)p.K;
+    const double outs = (double)p.nseg * p.M * p.N;
+    const double bytes = 2.0 * p.nseg * ((double)p.M * p.lda + (p.K - p.lda > 0 ? p.K - p.lda : 0)) + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0)) + 2.0 * p.N * p.K;
+    si_prof_begin(ctx, "lingemm_bf16_128x128", 2.0 * macs, bytes, st);
+    hipLaunchKernelGGL(lingemm_kernel, dim3((unsigned)(p.nseg * mtiles * (p.N / LG_BN))), dim3(LG_NT), lds, st, p);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}

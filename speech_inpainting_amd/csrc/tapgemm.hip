@@ -751,6 +751,23 @@ int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t
     if ((long)p.M * p.ldo + p.ooff < p.olimit)
         return si_fail(ctx, SI_EINVAL, "tapgemm: olimit=%ld must not exceed M*ldo+ooff=%ld (rows >= M are masked by the range check)",
                        p.olimit, (long)p.M * p.ldo + p.ooff);
+    // the encoder's bf16 GEMMs and strided convolutions on operand-ready activations: the dedicated kernel (lingemm.hip)
+    if (p.lingemm && math == SI_MATH_BF16 && p.x16 && p.groups == 1 && p.pad == 0 && p.dil == 1 && p.pro_slope == 1.f && p.alpha == 1.f &&
+        !p.accumulate && !p.res16 && !p.acc16 && p.out16_slope == 1.f && p.ooff == 0 && (p.ntaps == 1 || p.ldx == p.Cin) && p.Npad == p.N &&
+        p.olimit == (long)p.M * p.ldo) {
+        LinGemmParams q{};
+        q.x16 = p.x16;
+        const long xelems = p.nseg > 1 ? (long)p.nseg * p.x_seg_stride : (long)p.Lin * p.ldx;
+        q.x_bytes = (int)(xelems * 2 < (1L << 31) ? xelems * 2 : 0);
+        q.lda = p.stride * p.ldx; q.x_seg_stride = p.nseg > 1 ? p.x_seg_stride : 0;
+        q.nseg = p.nseg; q.M = p.M; q.K = p.ntaps * p.Cin;
+        q.w = static_cast<const unsigned short*>(p.w); q.w_bytes = p.ntaps * p.Npad * p.Cin * 2;
+        q.N = p.N; q.Cin = p.Cin; q.ntaps = p.ntaps; q.w_tap_stride = (long)p.Npad * p.Cin;
+        q.bias = p.bias; q.res = p.res; q.out = p.out; q.out16 = p.out16; q.ldo = p.ldo; q.o_seg_stride = p.nseg > 1 ? p.o_seg_stride : 0;
+        q.act = p.act;
+        const int rc = si_launch_lingemm(ctx, q, st);
+        if (rc <= 0) return rc;
+    }
     const bool k32 = (p.Cin % 32 == 0);
     switch (math) {
         case SI_MATH_F32: return k32 ? launch_math<SI_MATH_F32, 32>(ctx, p, st) : launch_math<SI_MATH_F32, 16>(ctx, p, st);

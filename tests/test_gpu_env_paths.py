@@ -38,6 +38,7 @@ COMBOS = [
     {"SI_VOC_OPREADY": "0", "SI_ENC_OPREADY": "0"},         # consumers convert fp32 activations while staging
     {"SI_ATT_BF16": "0"},                                    # bf16 encoder with the exact-fp32 attention kernel
     {"SI_VOC_RES16": "0", "SI_VOC_OPREADY": "0", "SI_ENC_OPREADY": "0", "SI_ATT_BF16": "0"},   # every non-default arithmetic path at once
+    {"SI_ENC_LINGEMM": "0"},                                 # encoder GEMMs on the generic tap-GEMM
 ]
 
 

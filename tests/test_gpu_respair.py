@@ -54,3 +54,35 @@ def test_fused_pairs_match_two_launch_form_and_oracle(B, Tm):
     if B > 1:
         one = _engine(varch, gsd, True).vocode(mel[1:2].cuda().contiguous(), stretch=False).cpu()
         assert torch.equal(one, fused[1:2])
+
+
+@pytest.mark.parametrize("arch", ["base", "large"])
+def test_lingemm_matches_tapgemm_in_the_bf16_encoder(arch):
+    """The dedicated bf16 GEMM kernel (lingemm.hip: Linear layers and the strided feature-extractor convolutions of the
+    base model as overlapping-row GEMMs) against the generic tap-GEMM on the same operands (SI_ENC_LINGEMM=0): identical
+    bf16 operands and fp32 accumulation, different summation order -> the 80-dim head outputs agree to ~5e-3 relative
+    (a bf16 activation copy that rounds the other way is a 2^-9 relative step), far inside the bf16 mode's own error."""
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import InpaintingEngine
+    harch = HubertArch.base() if arch == "base" else HubertArch.large()
+    varch = VocoderArch.tiny()
+    hsd, gsd, cb = synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook(50)
+    wave = synth.synth_wave(3, 24000, 91).cuda()
+    outs = {}
+    for flag in ("1", "0"):
+        os.environ["SI_ENC_LINGEMM"] = flag
+        try:
+            eng = InpaintingEngine(harch, varch, 50, "cuda:0", "bf16", "fp32").load_state(hsd, gsd, cb)
+        finally:
+            os.environ.pop("SI_ENC_LINGEMM", None)
+        eng.ctx.profile_start(4000)
+        outs[flag] = eng.encode(wave).cpu()
+        names = {e["name"] for e in eng.ctx.profile_stop()}
+        assert ("lingemm_bf16_128x128" in names) == (flag == "1"), names        # the kernel under test actually ran
+    ref = InpaintingEngine(harch, varch, 50, "cuda:0", "fp32", "fp32").load_state(hsd, gsd, cb).encode(wave).cpu()
+    d = rms(outs["1"], outs["0"]) / rms(outs["0"])
+    e1, e0 = rms(outs["1"], ref) / rms(ref), rms(outs["0"], ref) / rms(ref)
+    print(f"{arch}: lingemm vs tapgemm {d:.3e} relative; vs the fp32 encoder: lingemm {e1:.3e}, tapgemm {e0:.3e}")
+    assert bool(torch.isfinite(outs["1"]).all())
+    assert d <= 1.2e-2 and e1 <= 2e-2 and e0 <= 2e-2

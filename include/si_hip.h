@@ -10,6 +10,9 @@
  *                           I_ea/predict.py:164-168,171,184-187 ; I_ea/loss_fn.py:44-47
  *   si_codebook_metrics  <- LossFunction.cos_sim loss + cos_sim_target_labels (row f-4)
  *                           I_ea/loss_fn.py:29-62 ; I_ea/predict.py:171-173
+ *   si_mel_metrics       <- Metrics.avg_cosine_sim / avg_d2_dist / rmse (row f-4)   I_ea/metrics.py:38-62
+ *   si_sisdr             <- Metrics.sisdr (row f-4)                                 I_ea/metrics.py:127-142
+ *   si_unit_frontend     <- CodeGenerator.forward's embedding / _upsample / concat front (row f-2)   I_da/src/model.py:79-119,148-189
  *   si_kmeans_assign     <- kmeans_model.predict(feats) (row f-2)   I_da/scripts/inpainting.py:204-205 ;
  *                           ApplyKmeans.__call__                    I_ea/dataset/km_label.py:20-24
  *   si_resample_poly     <- librosa.load(..., sr=22050 / 16000) resampling (row f-3)   I_ea/predict.py:79-80
@@ -130,6 +133,17 @@ int si_workspace_bytes(si_ctx* ctx, int B, int N, int Tm, size_t* out);
 int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len, int normalize,
                       int B, int N, float* out_feats, void* workspace, size_t workspace_bytes, si_stream_t stream);
 
+/* The same for RIGHT-PADDED batches -- `CustomModel.forward(input_values, attention_mask)` with a mask that is not all ones
+ * (I_ea/model.py:80-85 -> modeling_hubert.py:921-932): valid_len (device int32 (B), samples) marks the real part of each clip.
+ * normalize != 0 reproduces the processor's padded normalisation (statistics over the real samples, padding = 0 after it);
+ * the feature extractor and the projection run over the whole padded input (HuBERT-base's GroupNorm therefore sees the
+ * padding, exactly as the reference's does), the padded frames of the projected states are zeroed and excluded as
+ * attention keys (:428-437, frame lengths by :664-689).  Outputs are defined on ALL T frames, as in the reference.
+ * valid_len = NULL is si_hubert_forward. */
+int si_hubert_forward_padded(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len,
+                             const int32_t* valid_len, int normalize, int B, int N, float* out_feats, void* workspace,
+                             size_t workspace_bytes, si_stream_t stream);
+
 /* Codeword decision + splice: for b, j < Lm:  label = argmax_k cos(feats[b, pos_b + j], C_k - mean(C));
  * mel[b, :, pos_b + j] = C_label.   feats (B, T, D); frame_pos device int32 (B); mel (B, D, Tm) in/out;
  * labels device int64 (B, Lm), may be NULL. */
@@ -159,6 +173,30 @@ int si_codebook_metrics(si_ctx* ctx, const float* feats, int B, int T, const int
  * labels device int64 (rows), sq_dist optional device fp32 (rows).  Needs no weights. */
 int si_kmeans_assign(si_ctx* ctx, const float* feats, int64_t rows, int D, const float* centroids, int K, int64_t* labels,
                      float* sq_dist, si_stream_t stream);
+
+/* Mel-domain metrics (row f-4, `Metrics.avg_cosine_sim / avg_d2_dist / rmse`, I_ea/metrics.py:38-62) of two mel segments
+ * per clip: mel_a, mel_b device fp32 (B, D, L) channels-first; center device fp32 (D) (the codebook mean the reference
+ * subtracts before the cosine) or NULL.  out3 device fp32 (B, 3) = {mean over frames of cos over bins of the centred
+ * frames; mean over frames of 20/ln10 * sqrt(mean over bins of ((a - mean_bins a) - (b - mean_bins b))^2); the same with one
+ * global mean}.  Needs no weights. */
+int si_mel_metrics(si_ctx* ctx, const float* mel_a, const float* mel_b, int B, int D, int L, const float* center, float* out3,
+                   si_stream_t stream);
+
+/* Scale-invariant SDR in dB (`Metrics.sisdr`, I_ea/metrics.py:127-142) of est against ref, device fp32 (B, n) each;
+ * out device fp32 (B).  eps = float32 machine epsilon, as np.finfo(x_est.dtype).eps for float32 waveforms. */
+int si_sisdr(si_ctx* ctx, const float* est, const float* ref, int B, int n, float* out, si_stream_t stream);
+
+/* I_da `CodeGenerator` front (I_da/src/model.py:148-189 in the look-up-table configuration of
+ * I_da/configs/LJSpeech/hubert_lut.json): out = concat_channels( emb_c[code], emb_p[f0_code], spk_emb ) with the shorter
+ * index series repeated frame-wise up to the longer (`_upsample`, :79-119; the lengths must divide) and the speaker
+ * embedding vector repeated over all frames.  code device int64 (B, Fc); f0_code device int64 (B, Fp) or NULL (no pitch
+ * part; the indices are what the fixed F0 VQ-VAE emits at :163-165 -- its quantiser is si_kmeans_assign's arg-min, its
+ * conv encoder is not part of this library); spk_emb device fp32 (B, E) or NULL; emb_c (Kc, E) / emb_p (Kp, E) device fp32
+ * tables owned by the caller (they live in the CodeGenerator checkpoint, not in this context).  out device fp32
+ * (B, nparts * E, max(Fc, Fp)) channels-first = the input of si_hifigan_forward(stretch = 0) for a generator whose
+ * num_mels = nparts * E (384 for hubert_lut.json).  An index outside its table yields NaN.  Needs no weights. */
+int si_unit_frontend(si_ctx* ctx, const int64_t* code, int Fc, const int64_t* f0_code, int Fp, const float* spk_emb,
+                     const float* emb_c, int Kc, const float* emb_p, int Kp, int E, int B, float* out, si_stream_t stream);
 
 /* Polyphase FIR resampler: the sample-rate conversions in front of the path, `librosa.load(path,
  * sr=22050)` / `sr=16000` at I_ea/predict.py:79-80.  y = upfirdn(taps, x, up, down)[pre_remove : pre_remove + n_out], i.e.

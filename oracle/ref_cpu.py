@@ -114,6 +114,29 @@ def mask_and_normalize(wave: torch.Tensor, mask_start: Sequence[int], mask_len: 
     return (x - mean) / torch.sqrt(var + 1e-7)
 
 
+def normalize_padded(waves: Sequence, padding_value: float = 0.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The HF processor on clips of DIFFERENT lengths (`padding=True`): each clip is normalised over its own samples, then
+    right-padded with `padding_value` (transformers/models/wav2vec2/feature_extraction_wav2vec2.py:78-97: normed =
+    (v - v[:len].mean()) / sqrt(v[:len].var() + 1e-7); normed[len:] = padding_value).  -> (input_values (B, Nmax) fp32,
+    attention_mask (B, Nmax) int32)."""
+    n = max(len(w) for w in waves)
+    x = torch.full((len(waves), n), float(padding_value), dtype=torch.float32)
+    m = torch.zeros(len(waves), n, dtype=torch.int32)
+    for b, w in enumerate(waves):
+        v = torch.as_tensor(w, dtype=torch.float32)
+        x[b, :len(v)] = (v - v.mean()) / torch.sqrt(v.var(unbiased=False) + 1e-7)
+        m[b, :len(v)] = 1
+    return x, m
+
+
+def feature_frame_lengths(arch, sample_lengths: torch.Tensor) -> torch.Tensor:
+    """`_get_feat_extract_output_lengths` (modeling_hubert.py:664-677): floor((n - k) / s) + 1 through the conv stack."""
+    n = sample_lengths.to(torch.long)
+    for k, s in zip(arch.conv_kernel, arch.conv_stride):
+        n = torch.div(n - k, s, rounding_mode="floor") + 1
+    return n
+
+
 def mask_samples_from_frames(frame_pos: int, frame_len: int) -> Tuple[int, int]:
     """Sample span the reference zeroes for a frame-level mask:
     ``[pos*320+80, (pos+len)*320+79-80)`` (I_ea/predict.py:133).  Returns (start, length)."""
@@ -167,14 +190,18 @@ def hubert_feature_extractor(sd, arch, x: torch.Tensor, prefix: str = "base_mode
     return h
 
 
-def hubert_attention(sd, arch, p: str, h: torch.Tensor) -> torch.Tensor:
-    """A6.  Eager attention: softmax(q k^T * d^-0.5) v, then out_proj (modeling_hubert.py:234-259,262-344)."""
+def hubert_attention(sd, arch, p: str, h: torch.Tensor, key_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A6.  Eager attention: softmax(q k^T * d^-0.5 + mask) v, then out_proj (modeling_hubert.py:234-259,262-344).
+    key_mask (B, T) bool: False = padded key, excluded for EVERY query (the additive -inf mask of :250-251, built from the
+    frame-level attention mask at :433-437)."""
     B, T, H = h.shape
     nh, hd = arch.num_attention_heads, arch.head_dim
     q = F.linear(h, sd[p + "q_proj.weight"].float(), sd[p + "q_proj.bias"].float()).view(B, T, nh, hd).transpose(1, 2)
     k = F.linear(h, sd[p + "k_proj.weight"].float(), sd[p + "k_proj.bias"].float()).view(B, T, nh, hd).transpose(1, 2)
     v = F.linear(h, sd[p + "v_proj.weight"].float(), sd[p + "v_proj.bias"].float()).view(B, T, nh, hd).transpose(1, 2)
     w = torch.matmul(q, k.transpose(2, 3)) * (hd ** -0.5)
+    if key_mask is not None:
+        w = w.masked_fill(~key_mask[:, None, None, :], torch.finfo(w.dtype).min)
     w = F.softmax(w, dim=-1)
     o = torch.matmul(w, v).transpose(1, 2).reshape(B, T, H)
     return F.linear(o, sd[p + "out_proj.weight"].float(), sd[p + "out_proj.bias"].float())
@@ -199,9 +226,12 @@ def hubert_pos_conv(sd, arch, prefix: str, h: torch.Tensor) -> torch.Tensor:
     return F.gelu(y).transpose(1, 2)
 
 
-def hubert_encode(sd, arch, x_norm: torch.Tensor, prefix: str = "base_model.", taps: Optional[dict] = None) -> torch.Tensor:
-    """A1..A8.  HubertModel.forward in eval mode with an all-ones attention mask
-    (modeling_hubert.py:878-947; encoder :407-476 post-LN, :550-623 pre-LN 'stable')."""
+def hubert_encode(sd, arch, x_norm: torch.Tensor, prefix: str = "base_model.", taps: Optional[dict] = None,
+                  attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A1..A8.  HubertModel.forward in eval mode (modeling_hubert.py:878-947; encoder :407-476 post-LN, :550-623 pre-LN
+    'stable').  attention_mask (B, N) 0/1 over SAMPLES (right-padded batches), or None = all ones: the feature extractor
+    and the projection see the whole padded input; the frame-level mask (:679-689) then zeroes the padded frames of the
+    projected states (:428-431 / :573-576) and excludes them as attention keys."""
     eps = arch.layer_norm_eps
     f = hubert_feature_extractor(sd, arch, x_norm, prefix).transpose(1, 2)          # (B, T, C)
     if taps is not None:
@@ -212,6 +242,11 @@ def hubert_encode(sd, arch, x_norm: torch.Tensor, prefix: str = "base_model.", t
     h = F.linear(f, sd[p + "projection.weight"].float(), sd[p + "projection.bias"].float())
     if taps is not None:
         taps["projected"] = h
+    key_mask = None
+    if attention_mask is not None:
+        flen = feature_frame_lengths(arch, attention_mask.sum(-1))
+        key_mask = torch.arange(h.shape[1])[None, :] < flen[:, None]
+        h = h * key_mask[:, :, None].to(h.dtype)
     h = h + hubert_pos_conv(sd, arch, prefix, h)
     e = prefix + "encoder."
     H = arch.hidden_size
@@ -223,11 +258,11 @@ def hubert_encode(sd, arch, x_norm: torch.Tensor, prefix: str = "base_model.", t
         L = f"{e}layers.{l}."
         if arch.do_stable_layer_norm:
             a = F.layer_norm(h, (H,), sd[L + "layer_norm.weight"].float(), sd[L + "layer_norm.bias"].float(), eps)
-            h = h + hubert_attention(sd, arch, L + "attention.", a)
+            h = h + hubert_attention(sd, arch, L + "attention.", a, key_mask)
             f2 = F.layer_norm(h, (H,), sd[L + "final_layer_norm.weight"].float(), sd[L + "final_layer_norm.bias"].float(), eps)
             h = h + hubert_ffn(sd, L + "feed_forward.", f2)
         else:
-            h = h + hubert_attention(sd, arch, L + "attention.", h)
+            h = h + hubert_attention(sd, arch, L + "attention.", h, key_mask)
             h = F.layer_norm(h, (H,), sd[L + "layer_norm.weight"].float(), sd[L + "layer_norm.bias"].float(), eps)
             h = h + hubert_ffn(sd, L + "feed_forward.", h)
             h = F.layer_norm(h, (H,), sd[L + "final_layer_norm.weight"].float(), sd[L + "final_layer_norm.bias"].float(), eps)
@@ -238,10 +273,11 @@ def hubert_encode(sd, arch, x_norm: torch.Tensor, prefix: str = "base_model.", t
     return h
 
 
-def custom_model_forward(sd, arch, x_norm: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
-    """A9.  CustomModel.forward: final_layers = LayerNorm(H) -> Linear(H, codebook_dim) on last_hidden_state
-    (I_ea/model.py:75-78,80-89).  Returns (B, T, codebook_dim)."""
-    h = hubert_encode(sd, arch, x_norm, "base_model.", taps)
+def custom_model_forward(sd, arch, x_norm: torch.Tensor, taps: Optional[dict] = None,
+                         attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A9.  CustomModel.forward(input_values, attention_mask): final_layers = LayerNorm(H) -> Linear(H, codebook_dim) on
+    last_hidden_state (I_ea/model.py:75-78,80-89).  Returns (B, T, codebook_dim)."""
+    h = hubert_encode(sd, arch, x_norm, "base_model.", taps, attention_mask)
     if taps is not None:
         taps["last_hidden"] = h
     h = F.layer_norm(h, (arch.hidden_size,), sd["final_layers.0.weight"].float(), sd["final_layers.0.bias"].float(), 1e-5)
@@ -278,6 +314,64 @@ def kmeans_assign(feats: torch.Tensor, centroids: torch.Tensor) -> torch.Tensor:
     x, c = feats.float(), centroids.float()
     dist = x.pow(2).sum(1, keepdim=True) - 2 * torch.matmul(x, c.T) + c.pow(2).sum(1)[None, :]
     return dist.argmin(dim=1)
+
+
+def mel_signal_metrics(t1: torch.Tensor, t2: torch.Tensor, center: torch.Tensor):
+    """f-4.  `Metrics.avg_cosine_sim`, `.avg_d2_dist`, `.rmse` (I_ea/metrics.py:38-62) on mel segments (80, L), same torch
+    calls in the same order; center = the (80,) vector the constructor stores as `centroids.unsqueeze(1)` (:26).
+    PARITY UNPINNED: I_ea/metrics.py cannot be imported (librosa / pystoi / pesq / speech_recognition absent, and its
+    `from torch.nn.functional import F` line fails on its own); these are its statements restated."""
+    c = center.reshape(-1, 1)
+    cos = F.cosine_similarity(t1 - c, t2 - c, dim=0).mean()                                   # :39-42
+    log_scale = 20 / torch.log(torch.tensor(10.0))                                            # :45
+    a, b = t1 - torch.mean(t1, dim=0), t2 - torch.mean(t2, dim=0)                             # :46-49
+    d2 = (log_scale * torch.sqrt(torch.mean((a - b) ** 2, dim=0))).mean()                     # :50-53
+    r = log_scale * torch.sqrt(torch.mean((a - b) ** 2))                                      # :61
+    return cos, d2, r
+
+
+def sisdr(x_est, x_ref) -> float:
+    """f-4.  `Metrics.sisdr` (I_ea/metrics.py:127-142), numpy, in the dtype of the inputs."""
+    import numpy as np
+
+    eps = np.finfo(x_est.dtype).eps
+    reference = x_ref.reshape(x_ref.size, 1)
+    estimate = x_est.reshape(x_est.size, 1)
+    rss = np.dot(reference.T, reference)
+    a = (eps + np.dot(reference.T, estimate)) / (rss + eps)
+    e_true = a * reference
+    e_res = estimate - e_true
+    return float(10 * np.log10((eps + (e_true ** 2).sum()) / (eps + (e_res ** 2).sum())))
+
+
+def code_generator_front(code: torch.Tensor, emb_c: torch.Tensor, f0_code: Optional[torch.Tensor] = None,
+                         emb_p: Optional[torch.Tensor] = None, spk_emb: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """f-2.  The front of `CodeGenerator.forward` (I_da/src/model.py:148-189, LUT configuration): embedding look-ups
+    (:153,161), `_upsample` of the shorter series (:79-119: unsqueeze + repeat(max // len) + view, i.e. frame-wise
+    repeat; a length that does not divide raises NotImplementedError at :110-112), channel concat (:169), speaker
+    embedding repeated over the frames (:175-176).  PARITY UNPINNED: `src.model` is not importable here (fairseq,
+    kaldi_io absent) and the reference holds no fixture for it; restated from the source text only."""
+    def upsample(sig: torch.Tensor, frames: int) -> torch.Tensor:
+        if sig.dim() == 2:
+            sig = sig.unsqueeze(2)
+        b, ch, t = sig.shape
+        rep = frames // t
+        sig = sig.unsqueeze(3).repeat(1, 1, 1, rep)
+        if (frames - t * rep) // rep > 0:
+            raise NotImplementedError("Padding condition signal - misalignment between condition features.")
+        return sig.reshape(b, ch, frames)
+
+    x = emb_c[code].transpose(1, 2)
+    if f0_code is not None:
+        p = emb_p[f0_code].transpose(1, 2)
+        if x.shape[-1] < p.shape[-1]:
+            x = upsample(x, p.shape[-1])
+        else:
+            p = upsample(p, x.shape[-1])
+        x = torch.cat([x, p], dim=1)
+    if spk_emb is not None:
+        x = torch.cat([x, upsample(spk_emb, x.shape[-1])], dim=1)
+    return x
 
 
 def cos_sim_loss(values: torch.Tensor, labels: torch.Tensor, centroids: torch.Tensor):

@@ -517,7 +517,7 @@ size_t encoder_ws_bytes(const si_model_desc& d, int B, int N) {
                (size_t)B * d.conv_dim[0] * 2;
     // bf16 operand-ready copies (encoder in bf16 mode): LN(features), hidden, attention output, FFN intermediate
     const size_t h16 = (BT * d.conv_dim[d.num_conv - 1] + 2 * BT * d.hidden_size + BT * d.intermediate_size) * 2;
-    return f * 4 + h16 + (size_t)B * 16 + si_conv0_partials_bytes(B, N) + 40 * 256;
+    return f * 4 + h16 + (size_t)B * 16 + (size_t)B * 4 + si_conv0_partials_bytes(B, N) + 41 * 256;
 }
 
 // Clips per vocoder pass.  Measured on MI355X (B = 32, fp32): 4 -> 109 ms/step, 8 -> 93, 16 -> 89, 32 -> 88: small
@@ -655,6 +655,11 @@ int si_workspace_bytes(si_ctx* ctx, int B, int N, int Tm, size_t* out) {
 
 int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len, int normalize, int B, int N,
                       float* out_feats, void* workspace, size_t workspace_bytes, si_stream_t stream) {
+    return si_hubert_forward_padded(ctx, wav, mask_start, mask_len, nullptr, normalize, B, N, out_feats, workspace, workspace_bytes, stream);
+}
+
+int si_hubert_forward_padded(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len, const int32_t* valid_len,
+                             int normalize, int B, int N, float* out_feats, void* workspace, size_t workspace_bytes, si_stream_t stream) {
     if (!ctx) return SI_EINVAL;
     if (!ctx->weights_ready) return si_fail(ctx, SI_ESTATE, "si_hubert_forward before weights were loaded");
     if (!wav || !out_feats || !workspace || B <= 0) return si_fail(ctx, SI_EINVAL, "si_hubert_forward: NULL / empty argument");
@@ -673,6 +678,7 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
 
     Carver W{static_cast<char*>(workspace), workspace_bytes};
     double* stats = reinterpret_cast<double*>(W.bytes((size_t)B * 16));
+    int32_t* vframes = valid_len ? reinterpret_cast<int32_t*>(W.bytes((size_t)B * 4)) : nullptr;
     double* partials = reinterpret_cast<double*>(W.bytes(si_conv0_partials_bytes(B, N)));
     float* affine = W.floats((size_t)B * d.conv_dim[0] * 2);
     float* cbuf[2] = {W.floats((size_t)B * cmax), W.floats((size_t)B * cmax)};
@@ -697,8 +703,9 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
 
     int rc;
     // A0 + A1: normalise fused into conv0
-    WaveNormParams wp{wav, mask_start, mask_len, B, N, e.L[1], d.conv_dim[0], d.conv_kernel[0], d.conv_stride[0], normalize};
+    WaveNormParams wp{wav, mask_start, mask_len, B, N, e.L[1], d.conv_dim[0], d.conv_kernel[0], d.conv_stride[0], normalize, valid_len};
     if ((rc = si_launch_wave_stats(ctx, wp, stats, st))) return rc;
+    if (valid_len && (rc = si_launch_frame_lengths(ctx, valid_len, B, d.num_conv, d.conv_kernel, d.conv_stride, e.T, vframes, st))) return rc;
     if (!d.feat_norm_layer) {
         // group-norm flavour in bf16 mode: the conv chain runs on operand-ready bf16 activations (conv0 and convs 1..n-2
         // write ONLY the bf16 operand of their single consumer; the last conv writes fp32 for the LayerNorm that follows)
@@ -740,6 +747,9 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     }
     if ((rc = linear(ctx, L.proj, pin, h, BT, SI_ACT_NONE, nullptr, st, d.feat_proj_layer_norm ? lnf16 : nullptr))) return rc;
     if ((rc = si_tap(ctx, "projected", h, BT * H, st))) return rc;
+    // right-padded batches: padded frames of the projected states are zeroed before the positional conv and excluded
+    // as attention keys (modeling_hubert.py:428-437 / 573-582)
+    if (vframes && (rc = si_launch_zero_padded_rows(ctx, h, B, T, H, vframes, st))) return rc;
     // A4: h2 = h + gelu(pos_conv(h) + b)
     {
         TapGemmParams p = gemm_params(ctx, L.pos);
@@ -761,7 +771,7 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
         const LayerW& Wl = L.layers[l];
         if (!d.stable_layer_norm) {       // post-LN (modeling_hubert.py:371-404); h16 = bf16(h) when e16
             if ((rc = linear(ctx, Wl.qkv, h, qkv, BT, SI_ACT_NONE, nullptr, st, h16))) return rc;
-            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16))) return rc;
+            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16, vframes))) return rc;
             if ((rc = linear(ctx, Wl.out, att, h2, BT, SI_ACT_NONE, h, st, att16))) return rc;
             if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h, BT, H, eps, 0, st, h16))) return rc;
             if ((rc = linear(ctx, Wl.ffn1, h, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16))) return rc;
@@ -770,7 +780,7 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
         } else {                          // pre-LN "stable" (modeling_hubert.py:504-547); residual adds are in place
             if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h2, BT, H, eps, 0, st, h16))) return rc;
             if ((rc = linear(ctx, Wl.qkv, h2, qkv, BT, SI_ACT_NONE, nullptr, st, h16))) return rc;
-            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16))) return rc;
+            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16, vframes))) return rc;
             if ((rc = linear(ctx, Wl.out, att, h, BT, SI_ACT_NONE, h, st, att16))) return rc;
             if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h2, BT, H, eps, 0, st, h16))) return rc;
             if ((rc = linear(ctx, Wl.ffn1, h2, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16))) return rc;
@@ -833,6 +843,35 @@ int si_kmeans_assign(si_ctx* ctx, const float* feats, int64_t rows, int D, const
     if (!feats || !centroids || !labels || rows < 0) return si_fail(ctx, SI_EINVAL, "si_kmeans_assign: NULL / bad argument");
     SI_HIP_CHECK(hipSetDevice(ctx->device));
     return si_launch_kmeans_assign(ctx, feats, (long)rows, D, centroids, K, labels, sq_dist, static_cast<hipStream_t>(stream));
+}
+
+int si_mel_metrics(si_ctx* ctx, const float* mel_a, const float* mel_b, int B, int D, int L, const float* center, float* out3,
+                   si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!mel_a || !mel_b || !out3) return si_fail(ctx, SI_EINVAL, "si_mel_metrics: NULL argument");
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    return si_launch_mel_metrics(ctx, mel_a, mel_b, B, D, L, center, out3, static_cast<hipStream_t>(stream));
+}
+
+int si_sisdr(si_ctx* ctx, const float* est, const float* ref, int B, int n, float* out, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!est || !ref || !out) return si_fail(ctx, SI_EINVAL, "si_sisdr: NULL argument");
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    return si_launch_sisdr(ctx, est, ref, B, n, out, static_cast<hipStream_t>(stream));
+}
+
+int si_unit_frontend(si_ctx* ctx, const int64_t* code, int Fc, const int64_t* f0_code, int Fp, const float* spk_emb, const float* emb_c,
+                     int Kc, const float* emb_p, int Kp, int E, int B, float* out, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!code || !emb_c || !out || B <= 0 || Fc <= 0 || E <= 0 || Kc <= 0) return si_fail(ctx, SI_EINVAL, "si_unit_frontend: NULL / empty argument");
+    if (f0_code && (!emb_p || Fp <= 0 || Kp <= 0)) return si_fail(ctx, SI_EINVAL, "si_unit_frontend: f0_code needs its embedding table");
+    if (f0_code) {
+        const int F = Fp > Fc ? Fp : Fc, s = Fp > Fc ? Fc : Fp;
+        // `_upsample` repeats each frame F // len times and refuses anything that does not fill F (I_da/src/model.py:104-112)
+        if (F % s) return si_fail(ctx, SI_EINVAL, "si_unit_frontend: %d and %d frames: misalignment between condition features", Fc, Fp);
+    }
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    return si_launch_unit_frontend(ctx, code, Fc, f0_code, Fp, spk_emb, emb_c, Kc, emb_p, Kp, E, B, out, static_cast<hipStream_t>(stream));
 }
 
 int si_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const float* taps, int ntaps, int up, int down,

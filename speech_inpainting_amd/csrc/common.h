@@ -95,6 +95,9 @@ struct WaveNormParams {           // A0 + A1 (group-norm flavour)
     int B, N, L1;                 // L1 = conv0 output length
     int C, K, S;                  // conv0 channels / kernel / stride
     int normalize;                // 0: wav is already zero-mean/unit-variance
+    const int32_t* valid_len;     // (B) or null: samples of each right-padded clip that are real; the rest is padding
+                                  // (statistics over the real samples only, padding reads as 0 AFTER the normalisation:
+                                  // transformers/models/wav2vec2/feature_extraction_wav2vec2.py:88-91)
 };
 
 int si_launch_wave_stats(si_ctx* ctx, const WaveNormParams& p, double* stats /*B*2: mean, rstd*/, hipStream_t st);
@@ -115,8 +118,14 @@ int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const flo
 // softmax(q k^T / sqrt(64)) v for head_dim 64; qkv (B, T, 3H) packed [q | k | v]; out (B, T, H)
 // out16 (optional): write the result as bf16 there INSTEAD of fp32 into out
 // bf16_products: with out16 given, run both products on bf16 MFMA (fp32 softmax); false keeps the exact-fp32 kernel
+// valid_frames (B) or null: keys >= valid_frames[b] are padding and excluded for every query (modeling_hubert.py:250-251)
 int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st,
-                        unsigned short* out16 = nullptr, bool bf16_products = true);
+                        unsigned short* out16 = nullptr, bool bf16_products = true, const int32_t* valid_frames = nullptr);
+// valid_frames[b] = conv-stack length of valid_len[b] samples (modeling_hubert.py:664-677), clamped to [1, T]
+int si_launch_frame_lengths(si_ctx* ctx, const int32_t* valid_len, int B, int nconv, const int32_t* kernels, const int32_t* strides,
+                            int T, int32_t* valid_frames, hipStream_t st);
+// x[b][t][:] = 0 for t >= valid_frames[b] (padded frames of the projected states, modeling_hubert.py:428-431)
+int si_launch_zero_padded_rows(si_ctx* ctx, float* x, int B, int T, int H, const int32_t* valid_frames, hipStream_t st);
 
 // cosine arg-max against centred centroids + splice of the raw centroid into mel (A10..A13)
 int si_launch_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,
@@ -136,6 +145,10 @@ int si_launch_kmeans_assign(si_ctx* ctx, const float* x, long rows, int D, const
 int si_launch_codebook_metrics(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,
                                const float* cb_centered, const float* cb_rnorm, int K, const int64_t* target, float* terms,
                                float* loss, int64_t* pred, float* cos_pt, hipStream_t st);
+
+// mel-domain and waveform metrics (metrics_kernels.hip; I_ea/metrics.py:38-62,127-142)
+int si_launch_mel_metrics(si_ctx* ctx, const float* a, const float* b, int B, int D, int L, const float* center, float* out, hipStream_t st);
+int si_launch_sisdr(si_ctx* ctx, const float* est, const float* ref, int B, int n, float* out, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // mel front-end kernels (frontend_kernels.hip)
@@ -178,6 +191,9 @@ int si_launch_respair(si_ctx* ctx, int C, const unsigned short* y16, unsigned sh
 // channels D..ldo-1 are written as zero.
 int si_launch_extend_mel(si_ctx* ctx, const float* mel, int B, int D, int Tm, int Tout, int stretch, float* out, int ldo,
                          hipStream_t st);
+// I_da CodeGenerator front (f-2): embedding look-ups + frame repeat + channel concat -> (B, nparts * E, F) channels-first
+int si_launch_unit_frontend(si_ctx* ctx, const int64_t* code, int Fc, const int64_t* f0_code, int Fp, const float* spk_emb,
+                            const float* emb_c, int Kc, const float* emb_p, int Kp, int E, int B, float* out, hipStream_t st);
 // leaky_relu(0.01) -> Conv1d(C -> 1, k, pad k/2) -> tanh ; x (B, L, C) channels-last -> wav (B, L)
 int si_launch_conv_post(si_ctx* ctx, const float* x, const float* w /*[k][C]*/, const float* bias, int B, int L, int C, int k,
                         float* wav, hipStream_t st, const unsigned short* x16 = nullptr /* raw fp16 input instead of x */);

@@ -47,8 +47,9 @@ __global__ __launch_bounds__(1024) void wave_stats_kernel(WaveNormParams p, doub
     const float* x = p.wav + (long)b * p.N;
     const int ms = p.mask_start ? p.mask_start[b] : 0;
     const int ml = p.mask_len ? p.mask_len[b] : 0;
+    const int nv = p.valid_len ? min(max(p.valid_len[b], 1), p.N) : p.N;      // real samples of a right-padded clip
     double s = 0.0, ss = 0.0;
-    for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
+    for (int i = threadIdx.x; i < nv; i += blockDim.x) {
         float v = x[i];
         if (i >= ms && i < ms + ml) v = 0.f;
         s += v;
@@ -63,15 +64,16 @@ __global__ __launch_bounds__(1024) void wave_stats_kernel(WaveNormParams p, doub
     if (threadIdx.x == 0) {
         double S = 0, SS = 0;
         for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { S += red[0][i]; SS += red[1][i]; }
-        const double mean = S / p.N;
-        double var = SS / p.N - mean * mean;
+        const double mean = S / nv;
+        double var = SS / nv - mean * mean;
         if (var < 0) var = 0;
         stats[2 * b] = mean;
         stats[2 * b + 1] = 1.0 / sqrt(var + 1e-7);
     }
 }
 
-__device__ __forceinline__ float load_norm(const float* x, int i, int ms, int ml, float mean, float rstd) {
+__device__ __forceinline__ float load_norm(const float* x, int i, int ms, int ml, float mean, float rstd, int nv) {
+    if (i >= nv) return 0.f;                                         // padding value, applied after the normalisation
     float v = x[i];
     if (i >= ms && i < ms + ml) v = 0.f;
     return (v - mean) * rstd;
@@ -93,7 +95,8 @@ __global__ __launch_bounds__(256) void conv0_lagsums_kernel(WaveNormParams p, co
     const int ms = p.mask_start ? p.mask_start[b] : 0, ml = p.mask_len ? p.mask_len[b] : 0;
     const float* x = p.wav + (long)b * p.N;
     const int win = (nt - 1) * S + K;
-    for (int i = threadIdx.x; i < win; i += 256) xs[i] = load_norm(x, t0 * S + i, ms, ml, mean, rstd);
+    const int nv = p.valid_len ? min(max(p.valid_len[b], 1), p.N) : p.N;
+    for (int i = threadIdx.x; i < win; i += 256) xs[i] = load_norm(x, t0 * S + i, ms, ml, mean, rstd, nv);
     __syncthreads();
     __shared__ double part[2][160];
     const int pr = threadIdx.x & 127, half = threadIdx.x >> 7;
@@ -168,7 +171,8 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(WaveNormParams p, cons
     const int ms = p.mask_start ? p.mask_start[b] : 0, ml = p.mask_len ? p.mask_len[b] : 0;
     const float* x = p.wav + (long)b * p.N;
     const int win = (nt - 1) * S + K;
-    for (int i = threadIdx.x; i < win; i += 256) xs[i] = load_norm(x, t0 * S + i, ms, ml, mean, rstd);
+    const int nv = p.valid_len ? min(max(p.valid_len[b], 1), p.N) : p.N;
+    for (int i = threadIdx.x; i < win; i += 256) xs[i] = load_norm(x, t0 * S + i, ms, ml, mean, rstd, nv);
     __syncthreads();
     const int tpr = C / 4;                       // threads per output row (float4 of channels each)
     const int rpp = 256 / tpr;                   // rows per pass
@@ -267,6 +271,37 @@ int si_launch_conv0_affine(si_ctx* ctx, const WaveNormParams& p, const double* s
     return conv0_apply(ctx, p, stats, w, affine, out, false, st);
 }
 
+// ------------------------------------------------------------------------------------------------ padded batches
+struct ConvStack { int n; int k[SI_MAX_CONV], s[SI_MAX_CONV]; };
+__global__ void frame_lengths_kernel(const int32_t* __restrict__ valid_len, int B, ConvStack cs, int T, int32_t* __restrict__ valid_frames) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int n = valid_len[b];
+    for (int i = 0; i < cs.n; ++i) n = n >= cs.k[i] ? (n - cs.k[i]) / cs.s[i] + 1 : 0;      // floor((n - k) / s) + 1
+    valid_frames[b] = min(max(n, 1), T);
+}
+int si_launch_frame_lengths(si_ctx* ctx, const int32_t* valid_len, int B, int nconv, const int32_t* kernels, const int32_t* strides,
+                            int T, int32_t* valid_frames, hipStream_t st) {
+    ConvStack cs{};
+    cs.n = nconv;
+    for (int i = 0; i < nconv; ++i) { cs.k[i] = kernels[i]; cs.s[i] = strides[i]; }
+    hipLaunchKernelGGL(frame_lengths_kernel, dim3((B + 63) / 64), dim3(64), 0, st, valid_len, B, cs, T, valid_frames);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+__global__ __launch_bounds__(256) void zero_padded_rows_kernel(float* __restrict__ x, int T, int H, const int32_t* __restrict__ valid_frames) {
+    const int b = blockIdx.y, t = blockIdx.x;
+    if (t < valid_frames[b]) return;
+    float* r = x + ((long)b * T + t) * H;
+    for (int i = threadIdx.x * 4; i < H; i += 1024) *reinterpret_cast<f32x4*>(r + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+int si_launch_zero_padded_rows(si_ctx* ctx, float* x, int B, int T, int H, const int32_t* valid_frames, hipStream_t st) {
+    if (H % 4) return si_fail(ctx, SI_EINVAL, "zero_padded_rows: width %d must be a multiple of 4", H);
+    hipLaunchKernelGGL(zero_padded_rows_kernel, dim3(T, B), dim3(256), 0, st, x, T, H, valid_frames);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // One wave per row.  C % 4 == 0, C <= 2048 (the row lives in 8 float4 registers per lane).
 template <bool GELU>
@@ -348,7 +383,7 @@ int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const flo
 
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                         unsigned short* __restrict__ out16, int T, int H,
-                                                        int heads) {
+                                                        int heads, const int32_t* __restrict__ valid_frames) {
     __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_LD];
     __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * ATT_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -357,6 +392,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const int q0 = blockIdx.x * 128 + wave * 32;
     const long ld = 3L * H;
     const float* base = qkv + (long)b * T * ld + h * 64;
+    const int Tk = valid_frames ? min(max(valid_frames[b], 1), T) : T;   // keys beyond it are padding (every query row still runs)
 
     // this lane's half of its query row, pre-scaled by head_dim^-0.5 = 2^-3 (exact)
     float qr[32];
@@ -375,7 +411,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float mrun = -INFINITY, lrun = 0.f;
 
-    for (int k0 = 0; k0 < T; k0 += ATT_KT) {
+    for (int k0 = 0; k0 < Tk; k0 += ATT_KT) {
         __syncthreads();
         // stage K and V tiles: 32 rows x 64 floats each; 256 threads x 2 float4 per matrix
         for (int idx = tid; idx < ATT_KT * 16; idx += 256) {
@@ -406,7 +442,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (key >= T) s[r] = -INFINITY;
+            if (key >= Tk) s[r] = -INFINITY;
             tmax = fmaxf(tmax, s[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -461,7 +497,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __restrict__ qkv, unsigned short* __restrict__ out16, int T,
-                                                             int H, int heads) {
+                                                             int H, int heads, const int32_t* __restrict__ valid_frames) {
     __shared__ __attribute__((aligned(16))) unsigned short Ks[ATT_KT * ATB_LDK];
     __shared__ __attribute__((aligned(16))) unsigned short Vt[64 * ATB_LDV];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -470,6 +506,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __rest
     const int q0 = blockIdx.x * 128 + wave * 32;
     const long ld = 3L * H;
     const float* base = qkv + (long)b * T * ld + h * 64;
+    const int Tk = valid_frames ? min(max(valid_frames[b], 1), T) : T;
 
     bf16x8 qb[4];                                          // query row, 8 dims per k-step and lane half, scaled by 2^-3
     {
@@ -488,7 +525,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __rest
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float mrun = -INFINITY, lrun = 0.f;
 
-    for (int k0 = 0; k0 < T; k0 += ATT_KT) {
+    for (int k0 = 0; k0 < Tk; k0 += ATT_KT) {
         __syncthreads();
         for (int idx = tid; idx < ATT_KT * 16; idx += 256) {
             const int r = idx >> 4, j = idx & 15;
@@ -525,7 +562,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (key >= T) s[r] = -INFINITY;
+            if (key >= Tk) s[r] = -INFINITY;
             tmax = fmaxf(tmax, s[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -571,14 +608,14 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __rest
 }
 
 int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st,
-                        unsigned short* out16, bool att_bf16) {
+                        unsigned short* out16, bool att_bf16, const int32_t* valid_frames) {
     if (heads <= 0 || H != heads * 64) return si_fail(ctx, SI_EINVAL, "attention kernel needs head_dim 64 (H=%d heads=%d)", H, heads);
     if (B <= 0 || T <= 0) return SI_OK;
     dim3 grid((T + 127) / 128, B * heads);
     // bf16 encoder mode (out16 given): the bf16-MFMA form; SI_ATT_BF16=0 at context creation keeps the exact-fp32 kernel
     si_prof_begin(ctx, (out16 && att_bf16) ? "attention_bf16" : "attention_f32", 4.0 * B * (double)T * T * H, 16.0 * B * T * H, st);   // 2*T^2*H MACs
-    if (out16 && att_bf16) hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, st, qkv, out16, T, H, heads);
-    else hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, qkv, out, out16, T, H, heads);
+    if (out16 && att_bf16) hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, st, qkv, out16, T, H, heads, valid_frames);
+    else hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, qkv, out, out16, T, H, heads, valid_frames);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

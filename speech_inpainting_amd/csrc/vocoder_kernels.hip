@@ -101,3 +101,44 @@ int si_launch_conv_post(si_ctx* ctx, const float* x, const float* w, const float
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------ f-2: CodeGenerator front
+// I_da/src/model.py:148-189 (the LUT configuration, configs/*/hubert_lut.json): emb_c = emb_c_table[code] (:151-153),
+// emb_p = emb_p_table[f0_code] (:160-161), the shorter of the two repeated frame-wise up to the longer (`_upsample`,
+// :79-119: out[t] = in[t div (F / len)], lengths must divide), channel concat (:169), the speaker embedding VECTOR repeated
+// over all frames and concatenated (:175-176; `emb_s = emb` at :157).  out (B, nparts * E, F) channels-first: the
+// generator's input (si_hifigan_forward, stretch = 0).  One thread per output element; an index outside its table
+// writes NaN (nn.Embedding would raise; a device kernel cannot).
+__global__ __launch_bounds__(256) void unit_frontend_kernel(const int64_t* __restrict__ code, int Fc, const int64_t* __restrict__ f0c, int Fp,
+                                                            const float* __restrict__ spk, const float* __restrict__ emb_c, int Kc,
+                                                            const float* __restrict__ emb_p, int Kp, int E, int F, int nparts,
+                                                            float* __restrict__ out) {
+    const int b = blockIdx.z, ch = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= F) return;
+    const int part = ch / E, e = ch - part * E;
+    float v;
+    if (part == 0) {
+        const long idx = code[(long)b * Fc + t / (F / Fc)];
+        v = (idx >= 0 && idx < Kc) ? emb_c[idx * E + e] : __builtin_nanf("");
+    } else if (part == 1 && f0c) {
+        const long idx = f0c[(long)b * Fp + t / (F / Fp)];
+        v = (idx >= 0 && idx < Kp) ? emb_p[idx * E + e] : __builtin_nanf("");
+    } else {
+        v = spk[(long)b * E + e];
+    }
+    out[((long)b * nparts * E + ch) * F + t] = v;
+}
+
+int si_launch_unit_frontend(si_ctx* ctx, const int64_t* code, int Fc, const int64_t* f0_code, int Fp, const float* spk_emb,
+                            const float* emb_c, int Kc, const float* emb_p, int Kp, int E, int B, float* out, hipStream_t st) {
+    const int F = (f0_code && Fp > Fc) ? Fp : Fc;
+    const int nparts = 1 + (f0_code ? 1 : 0) + (spk_emb ? 1 : 0);
+    si_prof_begin(ctx, "unit_frontend", 0.0, 4.0 * B * nparts * E * (double)F, st);
+    hipLaunchKernelGGL(unit_frontend_kernel, dim3((F + 255) / 256, nparts * E, B), dim3(256), 0, st, code, Fc, f0_code, Fp, spk_emb, emb_c, Kc,
+                       emb_p, Kp, E, F, nparts, out);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}

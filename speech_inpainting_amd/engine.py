@@ -54,8 +54,9 @@ class InpaintingEngine:
 
     # ---- the three stages
     def encode(self, wave16: torch.Tensor, mask_start: Optional[torch.Tensor] = None, mask_len: Optional[torch.Tensor] = None,
-               normalize: bool = True) -> torch.Tensor:
-        return self.ctx.hubert_forward(wave16, mask_start, mask_len, normalize)
+               normalize: bool = True, valid_len: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """valid_len (B,) int32: real samples per clip of a RIGHT-PADDED batch (the reference's attention_mask.sum(-1))."""
+        return self.ctx.hubert_forward(wave16, mask_start, mask_len, normalize, valid_len)
 
     def splice(self, feats: torch.Tensor, frame_pos: torch.Tensor, lm: int, mel: torch.Tensor) -> torch.Tensor:
         return self.ctx.codebook_splice(feats, frame_pos, lm, mel)
@@ -124,9 +125,10 @@ class InpaintingEngine:
 # Drop-in module wrappers (same call signatures as the reference's nn.Modules)
 # ------------------------------------------------------------------------------------------------------------------
 class CustomModel:
-    """`CustomModel.forward` (I_ea/model.py:80-89): processor-normalised input_values (B, N) -> (B, T, codebook_dim).
-    attention_mask must be all ones (every BASELINE config uses full-length clips; padded batches are bucketed by
-    exact length instead)."""
+    """`CustomModel.forward(input_values, attention_mask)` (I_ea/model.py:80-89): processor-normalised input_values (B, N)
+    -> (B, T, codebook_dim).  attention_mask (B, N) 0/1 marks the real samples of a RIGHT-PADDED batch (what the HF
+    processor emits with padding=True): the padded frames are zeroed after the projection and excluded as attention
+    keys, as modeling_hubert.py:921-932,428-437 does; the output is defined on all T frames, like the reference's."""
 
     def __init__(self, engine: InpaintingEngine):
         self.engine = engine
@@ -140,10 +142,15 @@ class CustomModel:
         return self
 
     def __call__(self, input_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if attention_mask is not None and not bool(attention_mask.bool().all()):
-            raise NotImplementedError("padded batches are not supported; group clips by exact length")
         x = input_values.to(self.engine.device, torch.float32).contiguous()
-        return self.engine.encode(x, None, None, normalize=False)
+        valid = None
+        if attention_mask is not None:
+            m = attention_mask.to(self.engine.device).bool()
+            if not bool(m.all()):
+                if m.shape != x.shape or bool((m[:, 1:] & ~m[:, :-1]).any()):
+                    raise ValueError("attention_mask must be (B, N) and right-padded (ones, then zeros), as the HF processor emits it")
+                valid = m.sum(-1).to(torch.int32).contiguous()
+        return self.engine.encode(x, None, None, normalize=False, valid_len=valid)
 
     forward = __call__
 
@@ -200,3 +207,71 @@ class LossFunction:
         """outputs (B, T, 80), mask_pos (B,) int32, mel (B, 80, Tm) modified in place -> labels (B, Lm)."""
         return self.engine.splice(outputs.contiguous(), mask_pos.to(self.engine.device, torch.int32).contiguous(),
                                   int(mask_len), mel)
+
+
+class CodeGenerator:
+    """`CodeGenerator.forward` of I_da/src/model.py:124-189 in its look-up-table configuration (hubert_lut.json: content
+    units + quantised F0 + speaker embedding -> 384 channels -> the unit HiFi-GAN, upsample rates 5, 4, 4, 2, 2): the
+    embedding / `_upsample` / concat front is si_unit_frontend, the generator is the engine's (a VocoderArch with
+    num_mels = 3 * embedding_dim).  `emb_c` / `emb_p` are the checkpoint's `emb_c.weight` / `emb_p.weight` tables.
+    The reference quantises F0 with its fixed VQ-VAE inside forward (:160-166); here the caller passes the indices
+    (`f0_code`), e.g. from `InpaintingEngine.ctx.kmeans_assign` on the encoder's output against the VQ codebook."""
+
+    def __init__(self, engine: InpaintingEngine, emb_c: torch.Tensor, emb_p: Optional[torch.Tensor] = None):
+        self.engine = engine
+        dev = engine.device
+        self.emb_c = emb_c.to(dev, torch.float32).contiguous()
+        self.emb_p = None if emb_p is None else emb_p.to(dev, torch.float32).contiguous()
+
+    def eval(self):
+        return self
+
+    def remove_weight_norm(self):
+        return None
+
+    def __call__(self, **kwargs) -> torch.Tensor:
+        """code (B, Frame) int64; f0_code (B, Frame_p) int64 (optional); emb (B, Emb) speaker embedding (optional)
+        -> (B, 1, Frame * hop) waveform."""
+        dev = self.engine.device
+        code = kwargs["code"].to(dev, torch.int64).contiguous()
+        f0c = kwargs.get("f0_code")
+        emb = kwargs.get("emb")
+        x = self.engine.ctx.unit_frontend(code, self.emb_c,
+                                          None if f0c is None else f0c.to(dev, torch.int64).contiguous(), self.emb_p,
+                                          None if emb is None else emb.to(dev, torch.float32).contiguous())
+        return self.engine.vocode(x, stretch=False).unsqueeze(1)
+
+    forward = __call__
+
+
+class Metrics:
+    """The signal metrics of `Metrics` (I_ea/metrics.py:12-142) on the GPU: `avg_cosine_sim`, `avg_d2_dist`, `rmse` on mel
+    segments (80, L) and `sisdr` on waveforms, same names and argument order.  The Whisper WER/CER and PESQ/STOI members
+    are third-party CPU code outside the hot path and are not provided.  `centroids` is what the
+    reference passes to the constructor: the (80,) codebook mean that `avg_cosine_sim` subtracts."""
+
+    def __init__(self, engine: InpaintingEngine, centroids: torch.Tensor):
+        self.engine = engine
+        self.center = centroids.reshape(-1).to(engine.device, torch.float32).contiguous()
+
+    def _pair(self, t1, t2):
+        dev = self.engine.device
+        return t1.to(dev, torch.float32).contiguous()[None], t2.to(dev, torch.float32).contiguous()[None]
+
+    def avg_cosine_sim(self, tensor1: torch.Tensor, tensor2: torch.Tensor) -> torch.Tensor:
+        a, b = self._pair(tensor1, tensor2)
+        return self.engine.ctx.mel_metrics(a, b, self.center)[0, 0]
+
+    def avg_d2_dist(self, tensor1: torch.Tensor, tensor2: torch.Tensor) -> torch.Tensor:
+        a, b = self._pair(tensor1, tensor2)
+        return self.engine.ctx.mel_metrics(a, b, None)[0, 1]
+
+    def rmse(self, tensor1: torch.Tensor, tensor2: torch.Tensor) -> torch.Tensor:
+        a, b = self._pair(tensor1, tensor2)
+        return self.engine.ctx.mel_metrics(a, b, None)[0, 2]
+
+    def sisdr(self, x_est, x_ref) -> float:
+        dev = self.engine.device
+        e = torch.as_tensor(x_est, dtype=torch.float32).reshape(1, -1).to(dev).contiguous()
+        r = torch.as_tensor(x_ref, dtype=torch.float32).reshape(1, -1).to(dev).contiguous()
+        return float(self.engine.ctx.sisdr(e, r)[0])

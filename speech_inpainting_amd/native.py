@@ -21,8 +21,8 @@ SI_MATH = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, "fp16": 3, "f16": 3}
 SI_MAX_CONV, SI_MAX_UPS, SI_MAX_RB, SI_MAX_DIL = 8, 8, 4, 4
 
 EXPORTS = ["si_version", "si_create", "si_destroy", "si_last_error", "si_load_weights", "si_alloc_weights",
-           "si_weights_device_ptr", "si_workspace_bytes", "si_hubert_forward", "si_codebook_splice",
-           "si_codebook_splice_labels", "si_codebook_metrics", "si_kmeans_assign", "si_resample_poly", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
+           "si_weights_device_ptr", "si_workspace_bytes", "si_hubert_forward", "si_hubert_forward_padded", "si_codebook_splice",
+           "si_codebook_splice_labels", "si_codebook_metrics", "si_kmeans_assign", "si_mel_metrics", "si_sisdr", "si_unit_frontend", "si_resample_poly", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
            "si_vocoder_samples", "si_profile_start", "si_profile_filter", "si_profile_stop",
            "si_debug_capture", "si_debug_size"]
 
@@ -120,10 +120,14 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.si_weights_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     lib.si_workspace_bytes.argtypes = [vp, i32, i32, i32, C.POINTER(sz)]
     lib.si_hubert_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
+    lib.si_hubert_forward_padded.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_codebook_splice.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp]
     lib.si_codebook_splice_labels.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp]
     lib.si_codebook_metrics.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.si_kmeans_assign.argtypes = [vp, vp, C.c_int64, i32, vp, i32, vp, vp, vp]
+    lib.si_mel_metrics.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.si_sisdr.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    lib.si_unit_frontend.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, vp, vp]
     lib.si_resample_poly.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.si_hifigan_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_mel_frames.argtypes = [i32]
@@ -242,18 +246,20 @@ class NativeContext:
 
     # ---- forward calls (all enqueue on torch's current stream)
     def hubert_forward(self, wav: torch.Tensor, mask_start: Optional[torch.Tensor], mask_len: Optional[torch.Tensor],
-                       normalize: bool = True) -> torch.Tensor:
+                       normalize: bool = True, valid_len: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """valid_len (B,) int32 on the device: real samples of each RIGHT-PADDED clip (None: every clip fills its row)."""
         assert wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2 and wav.is_contiguous()
         B, N = wav.shape
         T = self.num_frames(N)
         if T < 1:
             raise ValueError(f"clip of {N} samples is too short")
-        for m in (mask_start, mask_len):
+        for m in (mask_start, mask_len, valid_len):
             assert m is None or (m.is_cuda and m.dtype == torch.int32 and m.numel() == B and m.is_contiguous())
         out = torch.empty(B, T, self.desc.codebook_dim, dtype=torch.float32, device=self.device)
         ws = self.workspace(B, N, 0)
-        self._check(self.lib.si_hubert_forward(self._h, _ptr(wav), _ptr(mask_start), _ptr(mask_len), int(normalize), B, N,
-                                               _ptr(out), _ptr(ws), ws.numel(), self._stream()), "si_hubert_forward")
+        self._check(self.lib.si_hubert_forward_padded(self._h, _ptr(wav), _ptr(mask_start), _ptr(mask_len), _ptr(valid_len),
+                                                      int(normalize), B, N, _ptr(out), _ptr(ws), ws.numel(), self._stream()),
+                    "si_hubert_forward_padded")
         return out
 
     def codebook_splice(self, feats: torch.Tensor, frame_pos: torch.Tensor, lm: int, mel: torch.Tensor) -> torch.Tensor:
@@ -304,6 +310,47 @@ class NativeContext:
         self._check(self.lib.si_kmeans_assign(self._h, _ptr(feats), rows, D, _ptr(centroids), centroids.shape[0], _ptr(labels),
                                               _ptr(dist), self._stream()), "si_kmeans_assign")
         return (labels, dist) if with_distance else labels
+
+    def mel_metrics(self, mel_a: torch.Tensor, mel_b: torch.Tensor, center: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """mel_a, mel_b (B, D, L) -> (B, 3) = avg_cosine_sim, avg_d2_dist, rmse of I_ea/metrics.py:38-62 per clip."""
+        for m in (mel_a, mel_b):
+            assert m.is_cuda and m.dtype == torch.float32 and m.dim() == 3 and m.is_contiguous()
+        assert mel_a.shape == mel_b.shape
+        B, D, L = mel_a.shape
+        assert center is None or (center.is_cuda and center.dtype == torch.float32 and center.numel() == D and center.is_contiguous())
+        out = torch.empty(B, 3, dtype=torch.float32, device=self.device)
+        self._check(self.lib.si_mel_metrics(self._h, _ptr(mel_a), _ptr(mel_b), B, D, L, _ptr(center), _ptr(out), self._stream()), "si_mel_metrics")
+        return out
+
+    def sisdr(self, est: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
+        """est, ref (B, n) waveforms -> (B,) SI-SDR in dB (I_ea/metrics.py:127-142)."""
+        for m in (est, ref):
+            assert m.is_cuda and m.dtype == torch.float32 and m.dim() == 2 and m.is_contiguous()
+        assert est.shape == ref.shape
+        out = torch.empty(est.shape[0], dtype=torch.float32, device=self.device)
+        self._check(self.lib.si_sisdr(self._h, _ptr(est), _ptr(ref), est.shape[0], est.shape[1], _ptr(out), self._stream()), "si_sisdr")
+        return out
+
+    def unit_frontend(self, code: torch.Tensor, emb_c: torch.Tensor, f0_code: Optional[torch.Tensor] = None,
+                      emb_p: Optional[torch.Tensor] = None, spk_emb: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """code (B, Fc) int64, emb_c (Kc, E); optional f0_code (B, Fp) int64 + emb_p (Kp, E); optional spk_emb (B, E)
+        -> (B, nparts * E, max(Fc, Fp)) fp32, the CodeGenerator's generator input."""
+        assert code.is_cuda and code.dtype == torch.int64 and code.dim() == 2 and code.is_contiguous()
+        assert emb_c.is_cuda and emb_c.dtype == torch.float32 and emb_c.dim() == 2 and emb_c.is_contiguous()
+        B, Fc = code.shape
+        Kc, E = emb_c.shape
+        Fp, Kp = 0, 0
+        if f0_code is not None:
+            assert f0_code.is_cuda and f0_code.dtype == torch.int64 and f0_code.is_contiguous() and f0_code.shape[0] == B
+            assert emb_p is not None and emb_p.is_cuda and emb_p.dtype == torch.float32 and emb_p.is_contiguous() and emb_p.shape[1] == E
+            Fp, Kp = f0_code.shape[1], emb_p.shape[0]
+        if spk_emb is not None:
+            assert spk_emb.is_cuda and spk_emb.dtype == torch.float32 and spk_emb.is_contiguous() and tuple(spk_emb.shape) == (B, E)
+        nparts = 1 + (f0_code is not None) + (spk_emb is not None)
+        out = torch.empty(B, nparts * E, max(Fc, Fp), dtype=torch.float32, device=self.device)
+        self._check(self.lib.si_unit_frontend(self._h, _ptr(code), Fc, _ptr(f0_code), Fp, _ptr(spk_emb), _ptr(emb_c), Kc, _ptr(emb_p), Kp,
+                                              E, B, _ptr(out), self._stream()), "si_unit_frontend")
+        return out
 
     def resample_poly(self, x: torch.Tensor, taps: torch.Tensor, up: int, down: int, pre_remove: int, n_out: int) -> torch.Tensor:
         """x (B, n_in) -> (B, n_out): upfirdn(taps, x, up, down)[pre_remove : pre_remove + n_out] (see audio.design_resampler)."""

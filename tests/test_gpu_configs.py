@@ -172,3 +172,46 @@ def test_ida_style_generator_geometry_matches_oracle():
     eng16 = InpaintingEngine(harch, varch, 20, "cuda:0", "fp32", "fp16").load_state(synth.synth_hubert_state(harch), gsd, synth.synth_codebook(20))
     got16 = eng16.vocode(x.cuda(), stretch=False).cpu()
     assert rms(got16, ref) <= 1e-3
+
+
+def test_ida_code_generator_front_and_decoder_match_oracle():
+    """SURVEY 8(f) row f-2, the rest: `CodeGenerator.forward` in the hubert_lut.json shape -- 100 content units and 20 F0
+    codes (embedding_dim 128), F0 series at half the unit rate (so `_upsample` repeats every F0 frame twice), one speaker
+    embedding per clip, 384 channels into the (5, 4, 4, 2, 2) generator -- against the oracle's restatement of
+    I_da/src/model.py:79-119,148-189 (parity unpinned: I_da is not importable) + the oracle's generator."""
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import CodeGenerator, InpaintingEngine
+    from speech_inpainting_amd.native import NativeError
+    varch = VocoderArch(upsample_rates=(5, 4, 4, 2, 2), upsample_kernel_sizes=(11, 8, 8, 4, 4), upsample_initial_channel=512,
+                        num_mels=384, sampling_rate=16000)
+    harch = HubertArch.tiny()
+    gsd = synth.synth_generator_state(varch)
+    eng = InpaintingEngine(harch, varch, 20, "cuda:0", "fp32", "fp32").load_state(synth.synth_hubert_state(harch), gsd, synth.synth_codebook(20))
+    g = torch.Generator().manual_seed(9)
+    B, Fc, Fp, E = 2, 28, 14, 128
+    emb_c, emb_p = torch.randn(100, E, generator=g) * 0.5, torch.randn(20, E, generator=g) * 0.5
+    code = torch.randint(0, 100, (B, Fc), generator=g)
+    f0c = torch.randint(0, 20, (B, Fp), generator=g)
+    spk = torch.randn(B, E, generator=g) * 0.5
+    x_ref = R.code_generator_front(code, emb_c, f0c, emb_p, spk)
+    assert x_ref.shape == (B, 384, Fc)
+    x = eng.ctx.unit_frontend(code.cuda(), emb_c.cuda(), f0c.cuda(), emb_p.cuda(), spk.cuda()).cpu()
+    assert torch.equal(x, x_ref)                                                    # pure data movement: bit-exact
+    # F0 at the higher rate instead: the content units are the ones repeated
+    x2 = eng.ctx.unit_frontend(code[:, :7].contiguous().cuda(), emb_c.cuda(), f0c.cuda(), emb_p.cuda(), None).cpu()
+    assert torch.equal(x2, R.code_generator_front(code[:, :7], emb_c, f0c, emb_p, None))
+    # misaligned lengths are refused, as `_upsample` refuses them
+    with pytest.raises(NativeError, match="misalignment"):
+        eng.ctx.unit_frontend(code[:, :9].contiguous().cuda(), emb_c.cuda(), f0c.cuda(), emb_p.cuda(), None)
+    # an index outside the table is visible, not a wild read
+    bad = code.clone(); bad[0, 3] = 100
+    assert bool(torch.isnan(eng.ctx.unit_frontend(bad.cuda(), emb_c.cuda())[0, :, 3]).all())
+    # the whole decoder through the module wrapper
+    wav = CodeGenerator(eng, emb_c, emb_p)(code=code, f0_code=f0c, emb=spk).cpu()
+    ref = R.generator_forward(gsd, varch, x_ref)
+    assert wav.shape == ref.shape == (B, 1, Fc * 320)
+    err, sig = rms(wav, ref), rms(ref)
+    print(f"CodeGenerator (LUT): waveform rms error {err:.3e} (signal rms {sig:.3f})")
+    assert err <= 1e-4 * max(sig, 1.0)

@@ -341,3 +341,71 @@ def test_loss_half_matches_reference_goldens():
         bad = tgt[:, :3].clone(); bad[1, 1] = K
         m2 = eng.codebook_metrics(feats, pos, 3, bad.contiguous())
         assert torch.isnan(m2["loss_terms"][1, 1]) and int(m2["pred_labels"][1, 1]) == -1
+
+
+@pytest.mark.parametrize("tag", ["group", "layer"])
+def test_padded_batches_match_reference_goldens(tag):
+    """`CustomModel(input_values, attention_mask)` on a right-padded batch (I_ea/model.py:80-85) against the reference's own
+    output on ALL frames (tests/golden/padded.npz): through the module wrapper with the processor's input_values, and
+    through si_hubert_forward_padded with the raw clips (normalisation over the real samples fused into conv0)."""
+    import os
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import CustomModel, InpaintingEngine
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "padded.npz"))
+    lens = [int(n) for n in z["lens"]]
+    seed = synth.DEFAULT_SEED
+    harch = HubertArch.tiny() if tag == "group" else HubertArch.tiny(conv_bias=True, feat_extract_norm="layer", do_stable_layer_norm=True)
+    varch = VocoderArch.tiny()
+    hsd = synth.synth_hubert_state(harch, seed)
+    ref = torch.from_numpy(z[f"{tag}_feats"])
+    waves = [synth.synth_wave(1, n, seed + 40 + i)[0] for i, n in enumerate(lens)]
+    x, m = R.normalize_padded(waves)
+    raw = torch.zeros(len(lens), max(lens))
+    for b, w in enumerate(waves):
+        raw[b, :len(w)] = w
+    vl = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    for enc, tol in (("fp32", 1e-4), ("bf16", 2e-2)):
+        eng = InpaintingEngine(harch, varch, 100, "cuda:0", enc, "fp32").load_state(hsd, synth.synth_generator_state(varch), synth.synth_codebook(100))
+        a = CustomModel(eng)(x.cuda(), m.cuda()).cpu()
+        b = eng.encode(raw.cuda(), None, None, normalize=True, valid_len=vl).cpu()
+        ea, eb = rms(a, ref) / rms(ref), rms(b, ref) / rms(ref)
+        print(f"padded {tag} {enc}: wrapper {ea:.3e}, raw + valid_len {eb:.3e} (relative rms on all frames)")
+        assert a.shape == ref.shape and ea <= tol and eb <= tol
+        if enc == "fp32":
+            # a full-length clip in a padded batch equals the same clip alone (its mask is all ones)
+            alone = eng.encode(raw[0:1, :lens[0]].contiguous().cuda()).cpu()
+            assert rms(alone[0], b[0]) <= 1e-5 * rms(ref)
+            # a mask that is not right-padded is refused
+            bad = m.clone(); bad[1, 10] = 0
+            with pytest.raises(ValueError, match="right-padded"):
+                CustomModel(eng)(x.cuda(), bad.cuda())
+
+
+def test_mel_and_waveform_metrics_match_oracle():
+    """f-4, the signal half: `Metrics.avg_cosine_sim / avg_d2_dist / rmse / sisdr` (I_ea/metrics.py:38-62,127-142) on the GPU
+    against the oracle's restatement of those statements (parity unpinned: the reference module is not importable)."""
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.engine import Metrics
+    c = load_case("tiny_group")
+    eng = _engine(c)
+    cb = c["cb"]
+    met = Metrics(eng, cb.mean(dim=0))
+    g = torch.Generator().manual_seed(3)
+    for L in (1, 10, 57, 300):
+        t1 = synth.synth_mel(1, L, 80, 200 + L)[0]
+        t2 = t1 + 0.3 * torch.randn(80, L, generator=g)
+        cos, d2, r = R.mel_signal_metrics(t1, t2, cb.mean(dim=0))
+        assert abs(float(met.avg_cosine_sim(t1, t2)) - float(cos)) <= 2e-6
+        assert abs(float(met.avg_d2_dist(t1, t2)) - float(d2)) <= 1e-5 * max(1.0, float(d2))
+        assert abs(float(met.rmse(t1, t2)) - float(r)) <= 1e-5 * max(1.0, float(r))
+    ref = synth.synth_wave(1, 22050, 5)[0].numpy()
+    for noise in (0.5, 1e-2, 1e-4, 0.0):
+        est = (0.7 * ref + noise * torch.randn(22050, generator=g).numpy()).astype(np.float32)
+        want, got = R.sisdr(est, ref), met.sisdr(est, ref)
+        print(f"sisdr noise {noise}: oracle {want:.4f} dB, GPU {got:.4f} dB")
+        assert abs(got - want) <= (1e-3 if noise > 0 else 3.0)         # the noiseless case is eps / rounding residue in both
+    batch = eng.ctx.mel_metrics(torch.stack([synth.synth_mel(1, 40, 80, 7)[0]] * 2).cuda(), torch.stack([synth.synth_mel(1, 40, 80, 8)[0]] * 2).cuda())
+    assert batch.shape == (2, 3) and torch.equal(batch[0], batch[1])

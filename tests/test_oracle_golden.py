@@ -79,3 +79,34 @@ def test_loss_half_matches_reference_lossfunction():
             assert np.array_equal(pred.numpy(), g[f"{tag}_{K}_pred"])
             assert abs(float(loss) - float(g[f"{tag}_{K}_loss"])) <= 1e-5 * max(1.0, abs(float(g[f"{tag}_{K}_loss"])))
             assert np.allclose(cpt.numpy(), g[f"{tag}_{K}_cos_pred_target"], atol=1e-6)
+
+
+def test_padded_batches_match_reference_goldens():
+    """Right-padded batches: the oracle's attention-mask branch (zeroed padded frames, excluded keys; modeling_hubert.py:
+    428-437,664-689) and its restatement of the processor's padded normalisation, against outputs of the reference's
+    `CustomModel.forward(input_values, attention_mask)` (tests/golden/padded.npz, tools/make_goldens.py::padded_cases)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "padded.npz"))
+    lens = [int(n) for n in z["lens"]]
+    seed = synth.DEFAULT_SEED
+    for tag, harch in (("group", HubertArch.tiny()),
+                       ("layer", HubertArch.tiny(conv_bias=True, feat_extract_norm="layer", do_stable_layer_norm=True))):
+        hsd = synth.synth_hubert_state(harch, seed)
+        waves = [synth.synth_wave(1, n, seed + 40 + i)[0] for i, n in enumerate(lens)]
+        assert np.allclose([float(hsd["final_layers.1.weight"][0, 0]), float(waves[1][100])], z[f"{tag}_probe"], atol=1e-7)
+        x, m = R.normalize_padded(waves)
+        assert np.allclose(x[:, :64].numpy(), z[f"{tag}_x_head"], atol=2e-6) and np.allclose(x[:, -64:].numpy(), z[f"{tag}_x_tail"], atol=2e-6)
+        with torch.no_grad():
+            feats = R.custom_model_forward(hsd, harch, x, attention_mask=m)
+        ref = torch.from_numpy(z[f"{tag}_feats"])
+        err = float((feats - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        assert feats.shape == ref.shape and err <= 2e-5, (tag, err)
+        # the mask matters: without it the padded clips differ
+        with torch.no_grad():
+            nomask = R.custom_model_forward(hsd, harch, x)
+        assert float((nomask[1] - ref[1]).pow(2).mean().sqrt()) > 1e-3

@@ -238,6 +238,33 @@ def loss_cases(out_dir, tmpdir):
     np.savez_compressed(os.path.join(out_dir, "loss_metrics.npz"), **rec)
 
 
+def padded_cases(out_dir):
+    """Right-padded batches through the reference's `CustomModel.forward(input_values, attention_mask)` (I_ea/model.py:80-89),
+    inputs from the HF processor with padding=True: both encoder flavours (group-norm / post-LN and layer-norm / pre-LN).
+    The fixture stores the clip lengths, probes of the processor output and the (B, T, 80) output on ALL frames."""
+    from transformers import Wav2Vec2FeatureExtractor
+    fe = Wav2Vec2FeatureExtractor(feature_size=1, sampling_rate=16000, padding_value=0.0, do_normalize=True,
+                                  return_attention_mask=True)
+    rec = {}
+    lens = [8000, 5611, 6913]
+    seed = synth.DEFAULT_SEED
+    for tag, harch in (("group", HubertArch.tiny()),
+                       ("layer", HubertArch.tiny(conv_bias=True, feat_extract_norm="layer", do_stable_layer_norm=True))):
+        hsd = synth.synth_hubert_state(harch, seed)
+        model = build_reference_custom_model(harch, hsd)
+        waves = [synth.synth_wave(1, n, seed + 40 + i)[0].numpy() for i, n in enumerate(lens)]
+        enc = fe(waves, sampling_rate=16000, padding=True, return_tensors="pt")
+        with torch.no_grad():
+            feats = model(enc.input_values, enc.attention_mask)
+        rec[f"{tag}_feats"] = feats.numpy()
+        rec[f"{tag}_x_head"] = enc.input_values[:, :64].numpy()
+        rec[f"{tag}_x_tail"] = enc.input_values[:, -64:].numpy()
+        rec[f"{tag}_probe"] = np.asarray([float(hsd["final_layers.1.weight"][0, 0]), float(waves[1][100])], np.float64)
+        print(f"padded {tag}: feats {tuple(feats.shape)} rms {rms(feats):.4f}")
+    rec["lens"] = np.asarray(lens, np.int32)
+    np.savez_compressed(os.path.join(out_dir, "padded.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
@@ -263,6 +290,7 @@ def main():
                                        blind=True),
         "extend_mel": lambda: extend_cases(a.out),
         "loss_metrics": lambda: loss_cases(a.out, tmp),
+        "padded": lambda: padded_cases(a.out),
     }
     for k, fn in cases.items():
         if a.only and k not in a.only.split(","):

@@ -1,61 +1,73 @@
-// respair.hip -- one ResBlock1 step  y' = y + conv2(lrelu(conv1(lrelu(y))))  as ONE kernel, for the narrow vocoder stages
-// (C = 32 / 64 channels) in the fp16 activation-stream mode (gfx950, wave64, MFMA).
+// respair.hip -- one ResBlock1 step  y' = y + conv2(lrelu(conv1(lrelu(y))))  as ONE kernel for the NARROW vocoder stages
+// (C = 32 / 64 channels) in the fp16 activation-stream mode (gfx950, wave64, v_mfma_f32_16x16x32_f16).
 //
 // I_ea/hifi_gan/models.py:36-43 runs, per (resblock, dilation): xt = lrelu(x); xt = c1(xt); xt = lrelu(xt); xt = c2(xt);
-// x = xt + x.  As two tap-GEMM launches the intermediate costs 4 of the pair's 10 bytes of HBM traffic per element, and
-// these stages sit on the memory side.  With N = C <= 64 one workgroup owns ALL channels of its rows,
-// so the intermediate can stay in LDS:
-//   phase 1   t[R1 rows] = lrelu(conv1(lrelu(y)) + b1)      rows [m0 - p2, m0 - p2 + R1), zero outside the clip
-//                                                           (conv2's zero padding applies to t), fp16 into LDS
-//   phase 2   out[BMo rows] = (conv2(t) + b2 + y) * alpha (+ previous out)      BMo = R1 - (k - 1)
-// The intermediate tile is written OVER the activation tile (dead once conv1 is done): 29.5 KB (C = 32) / 62 KB (C = 64)
-// of LDS per workgroup, i.e. five / two resident workgroups per CU.
-// conv1 is recomputed on the k - 1 halo rows between neighbouring tiles (1-8 %).  Weight slabs (C x C per tap) stream
-// through a double buffer for both convolutions; activations arrive as raw fp16 (leaky-ReLU applied while staging), the
-// residual is re-read from global (L2-hot) in the epilogue, which is row-contiguous (8-byte accesses after an LDS
-// transpose, as tapgemm.hip's).  Arithmetic is that of the two-launch form in the same mode: fp16 operands, fp32
-// accumulate, the intermediate rounded to fp16 once.
+// x = xt + x.  With N = C <= 64 one workgroup owns ALL channels of its rows, so the pair's intermediate stays in LDS
+// (respair_wide.hip is the same kernel for C = 128 / 256; the description of the phases is there).  What differs here:
+//   * a K step of the MFMA (32 channels) is half or all of C, so the unit of weight streaming is a GROUP OF TAPS, not a
+//     channel chunk: C = 32 holds all taps of a convolution in one slab (both convolutions of the pair are resident
+//     after the prologue: no streaming at all), C = 64 streams slabs of 4 taps (32 KB) through the double buffer.  The
+//     round-1 kernel re-staged a C x C slab and crossed a workgroup barrier for EVERY tap -- 4 to 16 MFMAs per barrier;
+//   * C = 32: 256 rows per 4-wave workgroup and 65 KB of LDS, two workgroups per CU (one's tile load and output pass
+//     overlap the other's MFMAs); C = 64: 512 rows per 8-wave workgroup;
+//   * LDS rows are 64 / 128 bytes: the chunk swizzle term of a row keeps chunk bit 0 (see swz16 in respair_wide.hip) and
+//     spreads the 2 or 4 rows of a 256-byte bank period.
+// Arithmetic is that of the two-launch tap-GEMM form in the same mode: fp16 operands, fp32 accumulate, the intermediate
+// rounded to fp16 once, (acc + b2 + y) * alpha (+ previous) in fp32, one rounding on store.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
 #include "common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-template <int C>
-__global__ __launch_bounds__(256, 3) void respair_kernel(const ResPairParams p) {
-    constexpr int R1 = 256;                              // intermediate rows per workgroup
-    constexpr int TM = R1 / 128;                         // 32-row tiles per wave (4 waves)
-    constexpr int TN = C / 32;
-    constexpr int LD = C + 8;                            // LDS row stride in halves (16-byte pad)
-    constexpr int KS = C / 16;                           // MFMA k-steps per tap
-    constexpr int V8 = C / 8;                            // 16-byte vectors per weight row
-    constexpr int WSLOTS = (C * V8 + 255) / 256;         // 16-byte weight vectors per thread and slab
-    constexpr int V4 = C / 4;                            // 8-byte (4-half) slots per activation row
-    constexpr int ASLOTS = C == 32 ? 10 : 20;            // (R1 + 50) * V4 / 256 rounded up
+constexpr int RPN_HALO = 50;                                          // (k - 1) * dil <= 50: k = 11, dil = 5
+
+// (chunk XOR term of a row) << 4 for 64- and 128-byte rows: chunk bit 0 is left alone (the two halves of a ds_read_b128
+// lane group of the 16x16x32 operand read differ in exactly that bit), the other bits spread the rows of a bank period
+template <int ROWB>
+__device__ __forceinline__ int rpn_swz(int row) {
+    if constexpr (ROWB == 128) return ((row >> 1) & 3) << 5;          // 8 chunks per row, 2 rows per 256 bytes
+    else return ((row >> 2) & 1) << 5;                                // 64-byte rows: 4 chunks per row, 4 rows per 256 bytes
+}
+
+template <int C, int R1, int WARPS_M, int TPS>
+__global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairParams p) {
+    static_assert(R1 == WARPS_M * 64 && (C == 32 || C == 64), "64-row wave tiles over all C channels");
+    constexpr int NT = 64 * WARPS_M;
+    constexpr int ROWB = C * 2;                                        // bytes per activation / intermediate / weight row
+    constexpr int ROWBO = C * 4;                                       // bytes per fp32 output-image row
+    constexpr int CPR = C / 8;                                         // 16-byte chunks per row
+    constexpr int KS = C / 32;                                         // MFMA k-steps (K = 32) per tap
+    constexpr int TN = C / 16;                                         // 16-column tiles per wave
+    constexpr int YBYTES = (R1 + RPN_HALO) * ROWB;
+    constexpr int WBYTES = TPS * C * ROWB;                             // one slab: TPS taps x [C n][C ci]
+    constexpr int WSLOTS = (WBYTES / 16 + NT - 1) / NT;
+    constexpr int YRPP = NT / CPR;                                     // rows per staging pass
+    constexpr int YSLOTS = (R1 + RPN_HALO + YRPP - 1) / YRPP;
+    constexpr int OXM = (C / 4 - 1) < 15 ? (C / 4 - 1) : 15;           // chunk XOR mask of the output image
+    static_assert(R1 * ROWBO <= YBYTES + 2 * WBYTES, "the output image reuses the operand region (not the biases behind it)");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Ys = smem;                                             // [R1 + 50][C] fp16: lrelu(y), later t (rows < R1)
+    char* const Ws = smem + YBYTES;                                    // [2][TPS][C][C] fp16 weight slabs
+    float* const Bs = reinterpret_cast<float*>(smem + YBYTES + 2 * WBYTES);   // [2][C] fp32: b1, b2
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int wm0 = wave * 64;
     const int k = p.k, d = p.dil;
     const int p1 = d * (k - 1) / 2, p2 = (k - 1) / 2;
     const int BMo = R1 - (k - 1);
     const int R0 = R1 + (k - 1) * d;
     const int b = blockIdx.y;
-    const int m0 = blockIdx.x * BMo;                     // first output row of this workgroup
-    const int t_row0 = m0 - p2;                          // global row of intermediate row 0
-    const int y_row0 = t_row0 - p1;                      // global row of staged activation row 0
-
-    unsigned short* Ys = reinterpret_cast<unsigned short*>(smem);          // [R0][LD]   lrelu(y), fp16
-    unsigned short* Ts = Ys;                                               // [R1][LD]   lrelu(conv1 + b1), fp16: OVER the activation
-                                                                           // tile, which is dead once conv1 is done (one extra barrier)
-    unsigned short* Ws = Ys + (size_t)(R1 + 50) * LD;                      // [2][C][LD] weight slab double buffer
+    const int m0 = blockIdx.x * BMo;                                   // first output row of this workgroup
+    const int t_row0 = m0 - p2;                                        // clip row of intermediate row 0
+    const int y_row0 = t_row0 - p1;                                    // clip row of staged activation row 0
 
     const long seg = (long)b * p.L * C;
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + seg), 0, p.L * C * 2, 0x00020000);
@@ -63,160 +75,211 @@ __global__ __launch_bounds__(256, 3) void respair_kernel(const ResPairParams p) 
     const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w1), 0, k * C * C * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w2), 0, k * C * C * 2, 0x00020000);
 
-    // ---- stage the activation tile: raw fp16 -> leaky-ReLU(0.1) on packed halves -> LDS (rows outside the clip read as zero)
+    // ---- weight slabs: slab s = taps [TPS * q, TPS * (q + 1)) of conv 1 (s < NS1) or conv 2 (q = s - NS1); the weights are
+    //      [tap][n][ci], so a slab is one contiguous run; taps past k read as zero through the descriptor
+    const int NS1 = (k + TPS - 1) / TPS, NS = 2 * NS1;
+    u32x4 rw[WSLOTS];
+    auto issueW = [&](int s) {
+        const bool second = s >= NS1;
+        const int soff = __builtin_amdgcn_readfirstlane((second ? s - NS1 : s) * WBYTES);
+#pragma unroll
+        for (int i = 0; i < WSLOTS; ++i)
+            rw[i] = __builtin_amdgcn_raw_buffer_load_b128(second ? w2rsrc : w1rsrc, (tid + i * NT) * 16, soff, 0);
+    };
+    auto storeW = [&](char* dst) {
+#pragma unroll
+        for (int i = 0; i < WSLOTS; ++i) {
+            const int q = tid + i * NT;                                // 16-byte chunk of the slab: row q / CPR, chunk q % CPR
+            if (WBYTES / 16 % NT == 0 || q < WBYTES / 16) {
+                const int r = q / CPR, c = q - r * CPR;
+                *reinterpret_cast<u32x4*>(dst + r * ROWB + ((c << 4) ^ rpn_swz<ROWB>(r))) = rw[i];
+            }
+        }
+    };
+
+    issueW(0);
+    if (tid < C / 2) {                                                 // biases -> LDS: the epilogues read them per lane
+        const int which = tid / (C / 4), c4 = (tid % (C / 4)) * 4;
+        *reinterpret_cast<f32x4*>(Bs + which * C + c4) = *reinterpret_cast<const f32x4*>((which ? p.b2 : p.b1) + c4);
+    }
+    // ---- the activation tile: raw fp16 -> leaky-ReLU(0.1) on the packed halves -> LDS (rows outside the clip read as zero)
     {
-        const int r0 = tid / V4, j = tid - r0 * V4;
-        f32x2 ra[ASLOTS];
+        const int yc = tid % CPR, yr0 = tid / CPR;
+        u32x4 ry[YSLOTS];
 #pragma unroll
-        for (int i = 0; i < ASLOTS; ++i)
-            ra[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(yrsrc, ((y_row0 + r0 + i * (256 / V4)) * C + 4 * j) * 2, 0, 0));
+        for (int i = 0; i < YSLOTS; ++i)
+            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, ((y_row0 + yr0 + i * YRPP) * C + 8 * yc) * 2, 0, 0);
+        storeW(Ws);                                                    // slab 0 has landed; the tile is still in flight
+        issueW(1);                                                     // slab 1 (NS >= 2) goes to the other buffer behind slab 0's MFMAs
 #pragma unroll
-        for (int i = 0; i < ASLOTS; ++i) {
-            const int r = r0 + i * (256 / V4);
-            if (r < R0) {
-                f16x4 h = __builtin_bit_cast(f16x4, ra[i]);
-                const f16x4 hs = h * (_Float16)0.1f;
+        for (int i = 0; i < YSLOTS; ++i) {
+            const int r = yr0 + i * YRPP;
+            if ((i + 1) * YRPP <= R1 || r < R0) {                       // rows < R1 always exist: no branch around their loads
+                f16x8 h = __builtin_bit_cast(f16x8, ry[i]);
+                const f16x8 hs = h * (_Float16)0.1f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = h[e] > (_Float16)0 ? h[e] : hs[e];
-                *reinterpret_cast<f16x4*>(Ys + (size_t)r * LD + 4 * j) = h;
+                for (int e = 0; e < 8; ++e) h[e] = h[e] > (_Float16)0 ? h[e] : hs[e];
+                *reinterpret_cast<f16x8*>(Ys + r * ROWB + ((yc << 4) ^ rpn_swz<ROWB>(r))) = h;
             }
         }
     }
-    // ---- weight slab streaming: slab s = tap s of conv1 for s < k, tap s - k of conv2 otherwise
-    const int w_r0 = tid / V8, w_j = tid - w_r0 * V8;
-    f32x4 rw[WSLOTS];
-    auto issueW = [&](int s) {
-        const bool second = s >= k;
-        const int soff = (second ? s - k : s) * C * C * 2;
-#pragma unroll
-        for (int i = 0; i < WSLOTS; ++i) {
-            const int r = w_r0 + i * (256 / V8);
-            const int voff = r < C ? (r * C + 8 * w_j) * 2 : (int)0x80000000;
-            rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? w2rsrc : w1rsrc, voff, soff, 0));
-        }
-    };
-    auto storeW = [&](unsigned short* dst) {
-#pragma unroll
-        for (int i = 0; i < WSLOTS; ++i) {
-            const int r = w_r0 + i * (256 / V8);
-            if (r < C) *reinterpret_cast<f32x4*>(dst + (size_t)r * LD + 8 * w_j) = rw[i];
-        }
-    };
-    issueW(0);
-    storeW(Ws);
-    issueW(1);                                           // k >= 2: slab 1 exists
     __syncthreads();
 
-    f32x16 acc[TM][TN];
+    f32x4 acc[4][TN];                                                  // [time tile i][channel tile j], transposed 16 x 16 tiles
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     zero_acc();
-    const int wrow0 = wave * (R1 / 4);                   // this wave's first row of the R1-row tile
-    // one tap: acc += A[rows wrow0 + .. (+ roff)] x W^T
-    auto compute = [&](const unsigned short* As, int roff, const unsigned short* Wc) {
+    int preW[TN];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            f16x8 a[TM], w[TN];
+    for (int j = 0; j < TN; ++j) {
+        const int n = 16 * j + r16;
+        preW[j] = n * ROWB + (rpn_swz<ROWB>(n) ^ (kg << 4));          // + tap * C * ROWB: C rows keep the swizzle term (C % 16 == 0)
+    }
+    // one slab = `ntap` taps x KS k-steps; step q = tap * KS + ks.  Fragments are double-buffered in registers: the reads
+    // of step q + 1 are issued before the MFMAs of step q (clamped to the last step: a harmless re-read).
+    auto compute = [&](int tap0, bool second, int ntap, const char* Wc) {
+        const int nsteps = ntap * KS;
+        auto load = [&](f16x8 (&y)[4], f16x8 (&w)[TN], int q) {
+            const int tl = KS == 1 ? q : q >> 1, ks = KS == 1 ? 0 : q & 1;
+            const int roff = second ? tap0 + tl : (tap0 + tl) * d;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f16x8*>(As + (size_t)(wrow0 + i * 32 + l31 + roff) * LD + 16 * ks + 8 * half);
+            for (int i = 0; i < 4; ++i) {
+                const int r = wm0 + 16 * i + r16 + roff;
+                y[i] = *reinterpret_cast<const f16x8*>(Ys + r * ROWB + ((rpn_swz<ROWB>(r) ^ (kg << 4)) ^ (ks * 64)));
+            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) w[j] = *reinterpret_cast<const f16x8*>(Wc + (size_t)(j * 32 + l31) * LD + 16 * ks + 8 * half);
+            for (int j = 0; j < TN; ++j) w[j] = *reinterpret_cast<const f16x8*>(Wc + tl * (C * ROWB) + (preW[j] ^ (ks * 64)));
+        };
+        auto mma = [&](const f16x8 (&y)[4], const f16x8 (&w)[TN]) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], w[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], y[i], acc[i][j], 0, 0, 0);
+        };
+        f16x8 ya[4], wa[TN], yb[4], wb[TN];
+        load(ya, wa, 0);
+        for (int q = 0; q < nsteps; q += 2) {
+            load(yb, wb, q + 1 < nsteps ? q + 1 : nsteps - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            mma(ya, wa);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            load(ya, wa, q + 2 < nsteps ? q + 2 : nsteps - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < nsteps) {
+                __builtin_amdgcn_s_setprio(1);
+                mma(yb, wb);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    const int nslab = 2 * k;
-    for (int s = 0; s < nslab; ++s) {
-        const unsigned short* Wc = Ws + (size_t)(s & 1) * C * LD;
-        if (s < k) {
-            compute(Ys, s * d, Wc);                      // conv1 tap s: intermediate row r reads activation row r + s*d
-        } else {
-            compute(Ts, s - k, Wc);                      // conv2 tap: output row o reads intermediate row o + tap
-        }
-        if (s == k - 1) {
-            __syncthreads();                             // every wave has finished reading the activation tile
-            // ---- phase-1 epilogue: bias, leaky-ReLU, zero outside the clip, fp16, into the intermediate tile
+    // Slab s is read from buffer s & 1.  Slab s + 1 -- requested during slab s - 1 -- is written to the other buffer behind
+    // slab s's MFMAs (that buffer was last read during slab s - 1; every wave has passed the barrier that ended it), then
+    // slab s + 2 is requested.
+    for (int s = 0; s < NS; ++s) {
+        const bool second = s >= NS1;
+        const int q = second ? s - NS1 : s;
+        const int tap0 = q * TPS;
+        compute(tap0, second, min(TPS, k - tap0), Ws + (s & 1) * WBYTES);
+        if (s == NS1 - 1) {
+            __syncthreads();                                           // every wave has finished reading the activation tile
+            // ---- phase-1 epilogue: bias, leaky-ReLU, zero outside the clip, fp16, over the activation tile
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < 4; ++i) {
+                const int m = wm0 + 16 * i + r16;
+                const int grow = t_row0 + m;
+                const float inside = (grow >= 0 && grow < p.L) ? 1.f : 0.f;    // as a factor: no branch per element
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int n = j * 32 + l31;
-                    const float bv = p.b1[n];
+                    const int n = 16 * j + 4 * kg;                     // this lane's four consecutive channels
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(Bs + n);
+                    f16x4 hv;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        const int grow = t_row0 + row;
-                        float v = acc[i][j][r] + bv;
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][e] + bv[e];
                         v = v > 0.f ? v : 0.1f * v;
-                        v = (grow >= 0 && grow < p.L) ? __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f) : 0.f;
-                        Ts[(size_t)row * LD + n] = __builtin_bit_cast(unsigned short, (_Float16)v);
+                        v = __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f) * inside;
+                        hv[e] = (_Float16)v;
                     }
+                    *reinterpret_cast<f16x4*>(Ys + m * ROWB + ((((n >> 3) << 4) ^ rpn_swz<ROWB>(m)) + 8 * (kg & 1))) = hv;
                 }
+            }
             zero_acc();
         }
-        if (s + 1 < nslab) {
-            storeW(Ws + (size_t)((s + 1) & 1) * C * LD);  // slab s+1 (in flight since the previous iteration)
-            if (s + 2 < nslab) issueW(s + 2);
-            __syncthreads();
+        if (s + 1 < NS) {
+            storeW(Ws + ((s + 1) & 1) * WBYTES);
+            if (s + 2 < NS) issueW(s + 2);
         }
+        __syncthreads();                                               // slab s + 1 (and, after phase 1, the intermediate) is visible
     }
 
-    // ---- final epilogue: 32x32 tiles transposed through a private LDS patch (the activation tile is dead), then
-    //      row-contiguous 8-byte residual reads / stores
-    __syncthreads();
-    float* const tl = reinterpret_cast<float*>(smem) + wave * (32 * 36);
-    const int lr = lane >> 3, lc = (lane & 7) * 4;
+    // ---- final epilogue: accumulators -> fp32 image of the output tile in LDS -> row-contiguous residual add + store.
+    //      A lane owns 8 consecutive channels of OPASS output rows; its residual / accumulate rows are requested first.
+    constexpr int ORPP = NT / CPR;
+    constexpr int OPASS = R1 / ORPP;
+    const int c8 = tid % CPR, or0 = tid / CPR;
+    u32x4 res[OPASS], prev[OPASS];
+    int goff[OPASS];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int it = 0; it < OPASS; ++it) {
+        const int o = or0 + it * ORPP;
+        const int grow = m0 + o;
+        goff[it] = (o < BMo && grow < p.L) ? (grow * C + 8 * c8) * 2 : (int)0x80000000;
+        res[it] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, goff[it], 0, 0);
+        if (p.accumulate) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, goff[it], 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = wm0 + 16 * i + r16;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = j * 32 + lc;
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.b2 + n);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tl[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = acc[i][j][r];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int o = wrow0 + i * 32 + lr + 8 * q;                     // output row inside the tile
-                const int grow = m0 + o;
-                const int off = (o < BMo && grow < p.L) ? (grow * C + n) * 2 : (int)0x80000000;
-                const f32x4 a = *reinterpret_cast<const f32x4*>(tl + (lr + 8 * q) * 36 + lc);
-                const f32x4 res = __builtin_convertvector(__builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(yrsrc, off, 0, 0)), f32x4);
-                f32x4 prev = {0.f, 0.f, 0.f, 0.f};
-                if (p.accumulate) prev = __builtin_convertvector(__builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(orsrc, off, 0, 0)), f32x4);
-                f16x4 h;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = (a[e] + b4[e] + res[e]) * p.alpha + prev[e];
-                    h[e] = (_Float16)__builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f);
-                }
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), orsrc, off, 0, 0);
-            }
+            const int co = 4 * j + kg;                                 // 16-byte chunk (4 channels) of the output row
+            *reinterpret_cast<f32x4*>(smem + m * ROWBO + ((co ^ (m & OXM)) << 4)) = acc[i][j];
         }
+    }
+    __syncthreads();
+    {
+        const f32x4 b2a = *reinterpret_cast<const f32x4*>(Bs + C + 8 * c8), b2b = *reinterpret_cast<const f32x4*>(Bs + C + 8 * c8 + 4);
+#pragma unroll
+        for (int it = 0; it < OPASS; ++it) {
+            const int o = or0 + it * ORPP;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + o * ROWBO + (((2 * c8) ^ (o & OXM)) << 4));
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem + o * ROWBO + (((2 * c8 + 1) ^ (o & OXM)) << 4));
+            const f16x8 rh = __builtin_bit_cast(f16x8, res[it]);
+            f16x8 ph = {};
+            if (p.accumulate) ph = __builtin_bit_cast(f16x8, prev[it]);
+            f16x8 out;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = e < 4 ? a0[e] : a1[e - 4];
+                const float bb = e < 4 ? b2a[e] : b2b[e - 4];
+                float v = (a + bb + (float)rh[e]) * p.alpha;
+                if (p.accumulate) v += (float)ph[e];
+                out[e] = (_Float16)__builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out), orsrc, goff[it], 0, 0);
+        }
+    }
 }
 
-template <int C>
+template <int C, int R1, int WARPS_M, int TPS>
 static int respair_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t st) {
-    constexpr int R1 = 256;
-    constexpr int LD = C + 8;
     const int BMo = R1 - (p.k - 1);
-    size_t lds = ((size_t)(R1 + 50) * LD + 2 * (size_t)C * LD) * 2;
-    lds = std::max(lds, (size_t)4 * 32 * 36 * sizeof(float));
-    auto kern = respair_kernel<C>;
+    const size_t lds = (size_t)(R1 + RPN_HALO) * C * 2 + 2 * (size_t)TPS * C * C * 2 + 2 * (size_t)C * 4;
+    auto kern = respair_kernel<C, R1, WARPS_M, TPS>;
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), lds)) return rc;
     char name[48];
     snprintf(name, sizeof(name), "respair_f16_c%d", C);
     const double elems = (double)p.B * p.L * C;
     si_prof_begin(ctx, name, 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 2.0 * 2.0 * p.k * C * C, st);
-    hipLaunchKernelGGL(kern, dim3((p.L + BMo - 1) / BMo, p.B), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((p.L + BMo - 1) / BMo, p.B), dim3(64 * WARPS_M), lds, st, p);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
@@ -226,9 +289,11 @@ static int respair_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t st) {
 int si_launch_respair(si_ctx* ctx, int C, const unsigned short* y16, unsigned short* out16, const void* w1, const void* w2,
                       const float* b1, const float* b2, int B, int L, int k, int dil, float alpha, int accumulate, hipStream_t st) {
     if ((C != 32 && C != 64 && C != 128 && C != 256) || k < 3 || k > 11 || (k & 1) == 0 || (k - 1) * dil > 50 ||
-        ((long)L + 512) * C * 2 >= (1L << 31)) return 1;
+        ((long)L + 1024) * C * 2 >= (1L << 31)) return 1;
     if (!b1 || !b2) return 1;
     ResPairParams p{y16, out16, static_cast<const unsigned short*>(w1), static_cast<const unsigned short*>(w2), b1, b2, B, L, k, dil, alpha, accumulate};
     if (C >= 128) return si_launch_respair_wide(ctx, C, p, st);
-    return C == 32 ? respair_launch<32>(ctx, p, st) : respair_launch<64>(ctx, p, st);
+    // C = 32: every tap of a convolution in one slab (11 x 2 KB), 256 rows, two 4-wave workgroups per CU
+    // C = 64: 4 taps per slab (32 KB), 512 rows, one 8-wave workgroup per CU
+    return C == 32 ? respair_launch<32, 256, 4, 11>(ctx, p, st) : respair_launch<64, 512, 8, 4>(ctx, p, st);
 }

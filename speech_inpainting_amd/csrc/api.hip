@@ -700,6 +700,10 @@ int si_hubert_forward_padded(si_ctx* ctx, const float* wav, const int32_t* mask_
     unsigned short* att16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * H * 2)) : nullptr;
     unsigned short* ffn16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * I * 2)) : nullptr;
     if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: encoder workspace carve exceeded its own estimate");
+    // bf16 mode with the bf16-MFMA attention: the QKV GEMM writes q | k | v as bf16 only (the rounding the attention
+    // kernel's staging would apply), into the storage of the fp32 matrix
+    const bool qkv_bf16 = e16 && ctx->opt_att_bf16;
+    unsigned short* qkv16 = reinterpret_cast<unsigned short*>(qkv);
 
     int rc;
     // A0 + A1: normalise fused into conv0
@@ -770,8 +774,10 @@ int si_hubert_forward_padded(si_ctx* ctx, const float* wav, const int32_t* mask_
     for (int l = 0; l < d.num_layers; ++l) {
         const LayerW& Wl = L.layers[l];
         if (!d.stable_layer_norm) {       // post-LN (modeling_hubert.py:371-404); h16 = bf16(h) when e16
-            if ((rc = linear(ctx, Wl.qkv, h, qkv, BT, SI_ACT_NONE, nullptr, st, h16))) return rc;
-            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16, vframes))) return rc;
+            if ((rc = linear(ctx, Wl.qkv, h, qkv_bf16 ? nullptr : qkv, BT, SI_ACT_NONE, nullptr, st, h16, qkv_bf16 ? qkv16 : nullptr))) return rc;
+            if (qkv_bf16) rc = si_launch_attention_bf16in(ctx, qkv16, B, T, H, d.num_heads, st, att16, vframes);
+            else rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16, vframes);
+            if (rc) return rc;
             if ((rc = linear(ctx, Wl.out, att, h2, BT, SI_ACT_NONE, h, st, att16))) return rc;
             if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h, BT, H, eps, 0, st, h16))) return rc;
             if ((rc = linear(ctx, Wl.ffn1, h, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16))) return rc;
@@ -779,8 +785,10 @@ int si_hubert_forward_padded(si_ctx* ctx, const float* wav, const int32_t* mask_
             if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h, BT, H, eps, 0, st, h16))) return rc;
         } else {                          // pre-LN "stable" (modeling_hubert.py:504-547); residual adds are in place
             if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h2, BT, H, eps, 0, st, h16))) return rc;
-            if ((rc = linear(ctx, Wl.qkv, h2, qkv, BT, SI_ACT_NONE, nullptr, st, h16))) return rc;
-            if ((rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16, vframes))) return rc;
+            if ((rc = linear(ctx, Wl.qkv, h2, qkv_bf16 ? nullptr : qkv, BT, SI_ACT_NONE, nullptr, st, h16, qkv_bf16 ? qkv16 : nullptr))) return rc;
+            if (qkv_bf16) rc = si_launch_attention_bf16in(ctx, qkv16, B, T, H, d.num_heads, st, att16, vframes);
+            else rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16, vframes);
+            if (rc) return rc;
             if ((rc = linear(ctx, Wl.out, att, h, BT, SI_ACT_NONE, h, st, att16))) return rc;
             if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h2, BT, H, eps, 0, st, h16))) return rc;
             if ((rc = linear(ctx, Wl.ffn1, h2, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16))) return rc;

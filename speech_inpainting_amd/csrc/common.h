@@ -121,6 +121,9 @@ int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const flo
 // valid_frames (B) or null: keys >= valid_frames[b] are padding and excluded for every query (modeling_hubert.py:250-251)
 int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st,
                         unsigned short* out16 = nullptr, bool bf16_products = true, const int32_t* valid_frames = nullptr);
+// bf16 encoder mode: q | k | v arrive as bf16 (B, T, 3H) from the QKV GEMM's epilogue; both products on bf16 MFMA
+int si_launch_attention_bf16in(si_ctx* ctx, const unsigned short* qkv16, int B, int T, int H, int heads, hipStream_t st,
+                               unsigned short* out16, const int32_t* valid_frames = nullptr);
 // valid_frames[b] = conv-stack length of valid_len[b] samples (modeling_hubert.py:664-677), clamped to [1, T]
 int si_launch_frame_lengths(si_ctx* ctx, const int32_t* valid_len, int B, int nconv, const int32_t* kernels, const int32_t* strides,
                             int T, int32_t* valid_frames, hipStream_t st);

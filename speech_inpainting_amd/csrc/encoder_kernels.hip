@@ -607,6 +607,128 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __rest
     }
 }
 
+// The same kernel on a bf16 q | k | v matrix (written as such by the QKV GEMM's epilogue: the rounding this kernel's staging
+// applied to the fp32 matrix, moved into the producer -- bit-identical scores, half the bytes written and read).  The
+// 2^-3 query scale is exact in bf16.
+__global__ __launch_bounds__(256) void attention_bf16in_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out16, int T,
+                                                               int H, int heads, const int32_t* __restrict__ valid_frames) {
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[ATT_KT * ATB_LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Vt[64 * ATB_LDV];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const long ld = 3L * H;
+    const unsigned short* base = qkv + (long)b * T * ld + h * 64;
+    const int Tk = valid_frames ? min(max(valid_frames[b], 1), T) : T;
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+    bf16x8 qb[4];
+    {
+        const int qrow = min(q0 + l31, T - 1);
+        const unsigned short* qp = base + (long)qrow * ld;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 t = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_t*>(qp + 16 * ks + 8 * half));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qb[ks][e] = (__bf16)((float)t[e] * 0.125f);
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float mrun = -INFINITY, lrun = 0.f;
+
+    for (int k0 = 0; k0 < Tk; k0 += ATT_KT) {
+        __syncthreads();
+        {   // K tile: 32 rows x 128 bytes, one 16-byte chunk per thread
+            const int r = tid >> 3, j = tid & 7;
+            u32x4_t kv = {0u, 0u, 0u, 0u};
+            if (k0 + r < T) kv = *reinterpret_cast<const u32x4_t*>(base + (long)(k0 + r) * ld + H + 8 * j);
+            *reinterpret_cast<u32x4_t*>(Ks + r * ATB_LDK + 8 * j) = kv;
+        }
+        {   // V transposed: a thread takes two consecutive keys x four dims and writes four packed 32-bit words
+            const int rp = tid >> 4, j = tid & 15;
+            u32x2_t w0 = {0u, 0u}, w1 = {0u, 0u};
+            if (k0 + 2 * rp < T) w0 = *reinterpret_cast<const u32x2_t*>(base + (long)(k0 + 2 * rp) * ld + 2 * H + 4 * j);
+            if (k0 + 2 * rp + 1 < T) w1 = *reinterpret_cast<const u32x2_t*>(base + (long)(k0 + 2 * rp + 1) * ld + 2 * H + 4 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned lo = (w0[e >> 1] >> (16 * (e & 1))) & 0xffffu, hi = (w1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                *reinterpret_cast<unsigned*>(Vt + (4 * j + e) * ATB_LDV + 2 * rp) = lo | (hi << 16);
+            }
+        }
+        __syncthreads();
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + l31 * ATB_LDK + 16 * ks + 8 * half);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qb[ks], s, 0, 0, 0);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (key >= Tk) s[r] = -INFINITY;
+            tmax = fmaxf(tmax, s[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mrun, tmax);
+        const float alpha = __expf(mrun - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - mnew); psum += s[r]; }
+        psum += __shfl_xor(psum, 32, 64);
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 pb;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pb[i] = (__bf16)s[8 * st + i];
+            const unsigned short* v0p = Vt + l31 * ATB_LDV + 16 * st + 4 * half;
+            const unsigned short* v1p = Vt + (32 + l31) * ATB_LDV + 16 * st + 4 * half;
+            bf16x8 va, vc;
+            const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(v0p), a1 = *reinterpret_cast<const bf16x4*>(v0p + 8);
+            const bf16x4 c0 = *reinterpret_cast<const bf16x4*>(v1p), c1 = *reinterpret_cast<const bf16x4*>(v1p + 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { va[e] = a0[e]; va[4 + e] = a1[e]; vc[e] = c0[e]; vc[4 + e] = c1[e]; }
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc, pb, o1, 0, 0, 0);
+        }
+    }
+    const int q = q0 + l31;
+    if (q < T) {
+        const float inv = 1.0f / lrun;
+        const long o = ((long)b * T + q) * H + h * 64;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = 8 * g4 + 4 * half;
+            f32x4 a = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
+            f32x4 c = {o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv};
+            *reinterpret_cast<bf16x4*>(out16 + o + d) = __builtin_convertvector(a, bf16x4);
+            *reinterpret_cast<bf16x4*>(out16 + o + 32 + d) = __builtin_convertvector(c, bf16x4);
+        }
+    }
+}
+
+int si_launch_attention_bf16in(si_ctx* ctx, const unsigned short* qkv16, int B, int T, int H, int heads, hipStream_t st, unsigned short* out16,
+                               const int32_t* valid_frames) {
+    if (heads <= 0 || H != heads * 64) return si_fail(ctx, SI_EINVAL, "attention kernel needs head_dim 64 (H=%d heads=%d)", H, heads);
+    if (B <= 0 || T <= 0) return SI_OK;
+    dim3 grid((T + 127) / 128, B * heads);
+    si_prof_begin(ctx, "attention_bf16", 4.0 * B * (double)T * T * H, 8.0 * B * T * H, st);
+    hipLaunchKernelGGL(attention_bf16in_kernel, grid, dim3(256), 0, st, qkv16, out16, T, H, heads, valid_frames);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
 int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st,
                         unsigned short* out16, bool att_bf16, const int32_t* valid_frames) {
     if (heads <= 0 || H != heads * 64) return si_fail(ctx, SI_EINVAL, "attention kernel needs head_dim 64 (H=%d heads=%d)", H, heads);

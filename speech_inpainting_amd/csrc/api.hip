@@ -76,6 +76,7 @@ struct si_ctx {
     std::vector<hipEvent_t> prof_pool;
     size_t prof_used = 0;
     int prof_open = -1;
+    int num_cus = 0;
     std::map<const void*, size_t> dyn_lds;   // per kernel: dynamic-LDS limit already raised on this context's device
     // arithmetic-path options, read from the environment when the context is created (all default to 1)
     bool opt_voc_opready = true, opt_voc_res16 = true, opt_enc_opready = true, opt_att_bf16 = true, opt_enc_lingemm = true;
@@ -133,6 +134,14 @@ int si_ensure_dyn_lds(si_ctx* ctx, const void* kern, size_t bytes) {
         have = bytes;
     }
     return SI_OK;
+}
+int si_num_cus(si_ctx* ctx) {
+    if (ctx->num_cus <= 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n <= 0) n = 256;
+        ctx->num_cus = n;
+    }
+    return ctx->num_cus;
 }
 void si_prof_end(si_ctx* ctx, hipStream_t st) {
     if (ctx->prof_open < 0) return;

@@ -20,6 +20,7 @@ void si_prof_end(si_ctx* ctx, hipStream_t st);
 // 64 KB default.  The high-water mark is kept per context (= per device): a process-wide cache would skip the call
 // for a second context on another GPU.
 int si_ensure_dyn_lds(si_ctx* ctx, const void* kern, size_t bytes);
+int si_num_cus(si_ctx* ctx);   // compute units of the context's device (persistent-kernel grids)
 
 typedef unsigned short bf16_t;   // raw bf16 bits
 

@@ -48,7 +48,9 @@ __device__ __forceinline__ int swz16(int row) {
 
 constexpr int RPW_HALO = 50;                                          // (k - 1) * dil <= 50: k = 11, dil = 5
 
-template <int C, int R1, int WARPS_M, int WARPS_N, int BKW>
+// ACC: the launch adds into the previous contents of out16 (last pair of the 2nd / 3rd resblock).  Without it the
+// registers of the accumulate rows are free and the NEXT tile's activation rows are prefetched under the last slab.
+template <int C, int R1, int WARPS_M, int WARPS_N, int BKW, bool ACC>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel(const ResPairParams p) {
     static_assert((WARPS_M * WARPS_N == 8 || WARPS_M * WARPS_N == 4) && R1 == WARPS_M * 64 && C == WARPS_N * 64, "64 x 64 wave tiles");
     static_assert(BKW == 128 || BKW == 64, "weight-slab depth");
@@ -79,14 +81,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
     const int p1 = d * (k - 1) / 2, p2 = (k - 1) / 2;
     const int BMo = R1 - (k - 1);
     const int R0 = R1 + (k - 1) * d;
-    const int b = blockIdx.y;
-    const int m0 = blockIdx.x * BMo;                                   // first output row of this workgroup
-    const int t_row0 = m0 - p2;                                        // clip row of intermediate row 0
-    const int y_row0 = t_row0 - p1;                                    // clip row of staged activation row 0
-
-    const long seg = (long)b * p.L * C;
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + seg), 0, p.L * C * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out16 + seg, 0, p.L * C * 2, 0x00020000);
+    // ---- persistent workgroups: tile = (clip, row block); a workgroup walks tiles blockIdx.x, + gridDim.x, ...
+    const int tiles_x = (p.L + BMo - 1) / BMo;
+    const int total = tiles_x * p.B;
     const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w1), 0, k * C * C * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w2), 0, k * C * C * 2, 0x00020000);
 
@@ -115,31 +112,53 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
 #pragma unroll
         for (int i = 0; i < WSLOTS; ++i) storeW1(dst, i);
     };
+    // the halo'd activation rows of a tile -> registers (rows outside the clip read as zero through the clip's descriptor)
+    const int yc = tid % CPRY, yr0 = tid / CPRY;
+    u32x4 ry[YSLOTS];
+    auto issueY = [&](int t) {
+        const int tb = t / tiles_x;
+        const int trow0 = (t - tb * tiles_x) * BMo - p2 - p1;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + (long)tb * p.L * C), 0, p.L * C * 2, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < YSLOTS; ++i)
+            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((trow0 + yr0 + i * YRPP) * C + 8 * yc) * 2, 0, 0);
+    };
 
-    issueW(0);
     if (tid < C / 2) {                                                 // biases -> LDS: the epilogues read them per lane
         const int which = tid / (C / 4), c4 = (tid % (C / 4)) * 4;
         *reinterpret_cast<f32x4*>(Bs + which * C + c4) = *reinterpret_cast<const f32x4*>((which ? p.b2 : p.b1) + c4);
     }
-    // ---- the activation tile: raw fp16 -> leaky-ReLU(0.1) on the packed halves -> LDS (rows outside the clip read as zero)
-    {
-        const int yc = tid % CPRY, yr0 = tid / CPRY;
-        u32x4 ry[YSLOTS];
+    int preW[4];
 #pragma unroll
-        for (int i = 0; i < YSLOTS; ++i)
-            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, ((y_row0 + yr0 + i * YRPP) * C + 8 * yc) * 2, 0, 0);
-        storeW(Ws);                                                    // slab 0 has landed; the tile is still in flight
-        issueW(1);                                                     // stays in registers until slab 0 starts (NS >= 6)
+    for (int j = 0; j < 4; ++j) {
+        const int n = wn0 + 16 * j + r16;
+        preW[j] = n * ROWBW + (swz16<ROWBW>(n) ^ (kg << 4));
+    }
+    issueW(0);
+    issueY(blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const int nxt = tile + (int)gridDim.x < total ? tile + (int)gridDim.x : tile;   // clamped: the loads below stay unconditional
+    const int b = tile / tiles_x;
+    const int m0 = (tile - b * tiles_x) * BMo;                         // first output row of this tile
+    const int t_row0 = m0 - p2;                                        // clip row of intermediate row 0
+    const long seg = (long)b * p.L * C;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + seg), 0, p.L * C * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out16 + seg, 0, p.L * C * 2, 0x00020000);
+
+    // ---- slab 0 and the activation tile (both requested one tile ago, or at kernel entry) -> LDS: raw fp16 -> leaky-ReLU(0.1)
+    //      on the packed halves
+    storeW(Ws);
+    issueW(1);                                                         // stays in registers until slab 0 starts (NS >= 6)
 #pragma unroll
-        for (int i = 0; i < YSLOTS; ++i) {
-            const int r = yr0 + i * YRPP;
-            if ((i + 1) * YRPP <= R1 || r < R0) {                       // rows < R1 always exist: no branch around their loads
-                f16x8 h = __builtin_bit_cast(f16x8, ry[i]);
-                const f16x8 hs = h * (_Float16)0.1f;
+    for (int i = 0; i < YSLOTS; ++i) {
+        const int r = yr0 + i * YRPP;
+        if ((i + 1) * YRPP <= R1 || r < R0) {                           // rows < R1 always exist: no branch around their loads
+            f16x8 h = __builtin_bit_cast(f16x8, ry[i]);
+            const f16x8 hs = h * (_Float16)0.1f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) h[e] = h[e] > (_Float16)0 ? h[e] : hs[e];
-                *reinterpret_cast<f16x8*>(Ys + r * ROWBY + ((yc << 4) ^ swz16<ROWBY>(r))) = h;
-            }
+            for (int e = 0; e < 8; ++e) h[e] = h[e] > (_Float16)0 ? h[e] : hs[e];
+            *reinterpret_cast<f16x8*>(Ys + r * ROWBY + ((yc << 4) ^ swz16<ROWBY>(r))) = h;
         }
     }
     __syncthreads();
@@ -152,12 +171,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     zero_acc();
-    int preW[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = wn0 + 16 * j + r16;
-        preW[j] = n * ROWBW + (swz16<ROWBW>(n) ^ (kg << 4));
-    }
     // one slab: acc^T += W[slab] * A[rows + roff][chunk columns]^T.  Fragments are double-buffered in registers: the
     // reads of k-step ks + 1 are issued before the MFMAs of k-step ks, so an MFMA never waits on a read issued just
     // ahead of it.  `hook(ks)` runs behind the MFMAs of k-step ks: the weight-slab stores and the next slab's loads are
@@ -243,12 +256,17 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
         if (++ch == NCH) { ch = 0; if (++tap == k) tap = 0; }
         __syncthreads();                                               // slab s + 1 (and, after phase 1, the intermediate) is visible
     }
-    // ---- last slab (tap k - 1, last chunk of conv 2).  The residual / accumulate rows of the output pass are requested
-    //      first, so that they arrive under its MFMAs: a lane owns 8 consecutive channels of OPASS output rows.
+    // ---- last slab (tap k - 1, last chunk of conv 2).  Without an accumulate operand the next tile's activation rows are
+    //      requested first, so that they travel under its MFMAs.
+    if constexpr (!ACC) issueY(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(tap, ch * (BKW * 2), Ws + ((NS - 1) & 1) * WBYTES, [](int) {});
+    // the residual / accumulate rows of the output pass travel under the output image's LDS round trip: a lane owns 8
+    // consecutive channels of OPASS output rows
     constexpr int ORPP = NT / CPRY;                                    // output rows per pass
     constexpr int OPASS = R1 / ORPP;
     const int c8 = tid % CPRY, or0 = tid / CPRY;
-    u32x4 res[OPASS], prev[OPASS];
+    u32x4 res[OPASS], prev[ACC ? OPASS : 1];
     int goff[OPASS];
 #pragma unroll
     for (int it = 0; it < OPASS; ++it) {
@@ -256,10 +274,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
         const int grow = m0 + o;
         goff[it] = (o < BMo && grow < p.L) ? (grow * C + 8 * c8) * 2 : (int)0x80000000;
         res[it] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, goff[it], 0, 0);
-        if (p.accumulate) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, goff[it], 0, 0);
+        if constexpr (ACC) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, goff[it], 0, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    compute(tap, ch * (BKW * 2), Ws + ((NS - 1) & 1) * WBYTES, [](int) {});
     __syncthreads();                                                   // every wave is done with the operand tiles
 
     // ---- final epilogue: accumulators -> fp32 image of the output tile in LDS -> row-contiguous residual add + store
@@ -273,6 +289,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
         }
     }
     __syncthreads();
+    issueW(0);                                                         // slab 0 of the next tile lands during the output pass
     {
         const f32x4 b2a = *reinterpret_cast<const f32x4*>(Bs + C + 8 * c8), b2b = *reinterpret_cast<const f32x4*>(Bs + C + 8 * c8 + 4);
 #pragma unroll
@@ -282,19 +299,22 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem + o * ROWBO + (((2 * c8 + 1) ^ (o & 15)) << 4));
             const f16x8 rh = __builtin_bit_cast(f16x8, res[it]);
             f16x8 ph = {};
-            if (p.accumulate) ph = __builtin_bit_cast(f16x8, prev[it]);
+            if constexpr (ACC) ph = __builtin_bit_cast(f16x8, prev[it]);
             f16x8 out;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float a = e < 4 ? a0[e] : a1[e - 4];
                 const float bb = e < 4 ? b2a[e] : b2b[e - 4];
                 float v = (a + bb + (float)rh[e]) * p.alpha;
-                if (p.accumulate) v += (float)ph[e];
+                if constexpr (ACC) v += (float)ph[e];
                 out[e] = (_Float16)__builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f);
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out), orsrc, goff[it], 0, 0);
         }
     }
+    if constexpr (ACC) issueY(nxt);                                    // (no registers to spare earlier in this variant)
+    __syncthreads();                                                   // the output image is consumed: the next tile may stage into LDS
+  }
 }
 
 template <int C, int R1, int WARPS_M, int WARPS_N, int BKW>
@@ -302,13 +322,17 @@ static int respair_wide_launch(si_ctx* ctx, const ResPairParams& p0, hipStream_t
     const ResPairParams& p = p0;
     const int BMo = R1 - (p.k - 1);
     const size_t lds = (size_t)(R1 + RPW_HALO) * C * 2 + 2 * (size_t)C * BKW * 2 + 2 * (size_t)C * 4;
-    auto kern = respair_wide_kernel<C, R1, WARPS_M, WARPS_N, BKW>;
+    auto kern = p.accumulate ? respair_wide_kernel<C, R1, WARPS_M, WARPS_N, BKW, true> : respair_wide_kernel<C, R1, WARPS_M, WARPS_N, BKW, false>;
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), lds)) return rc;
+    // one persistent workgroup per CU (144-157 KB of LDS each); SI_RP_PERSIST=0 launches one workgroup per tile instead
+    static const int persist = getenv("SI_RP_PERSIST") ? atoi(getenv("SI_RP_PERSIST")) : 1;
+    const int total = ((p.L + BMo - 1) / BMo) * p.B;
+    const int grid = persist ? std::min(total, si_num_cus(ctx)) : total;
     char name[48];
     snprintf(name, sizeof(name), "respair_f16_c%d", C);
     const double elems = (double)p.B * p.L * C;
     si_prof_begin(ctx, name, 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 2.0 * 2.0 * p.k * C * C, st);
-    hipLaunchKernelGGL(kern, dim3((p.L + BMo - 1) / BMo, p.B), dim3(64 * WARPS_M * WARPS_N), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WARPS_M * WARPS_N), lds, st, p);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

@@ -14,6 +14,10 @@
 // clock under load (tools/ubench/mfma_rate.hip), a 64-deep K chunk feeds 32 MFMAs per wave between barriers instead of
 // 8, and the output goes through an LDS image so that every global access is a whole row segment.
 //
+// (Measured and rejected: a 256 x 128 tile with eight waves and one workgroup per CU for the large-M convolutions --
+// a quarter fewer operand bytes out of L2 per flop -- ran conv1 / conv2 at 520 / 269 us against 481 / 248: what these
+// GEMMs need is the second resident workgroup, not fewer bytes.)
+//
 // Structure (as respair_wide.hip): one 4-wave workgroup per 128 x 128 tile, two workgroups per CU.  K chunks of 64
 // stream global -> registers -> LDS through a double buffer with the stores spread behind the MFMA blocks; one barrier
 // per chunk.  Orientation D^T = W * A^T: a lane holds one output row (column l & 15) and four consecutive output

@@ -40,6 +40,11 @@ MASK_FRAMES = 10          # 200 ms
 GFLOP_PER_CLIP = 268.3    # algorithmic, BASELINE.md section 2
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0, "f16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks
 MFMA_PER_PRODUCT = {"f32": 1, "bf16": 1, "bf16x3": 3, "f16": 1}
+# What a dense 16-bit MFMA stream SUSTAINS on this chip (the clock falls under matrix load): measured with
+# tools/ubench/mfma_rate.hip on every CU, random operands -- v_mfma_f32_16x16x32 1.82 PFLOP/s (registers only or LDS-fed),
+# v_mfma_f32_32x32x16 1.48 PFLOP/s from registers, 1.37 LDS-fed (profiles/r02_ubench_mfma_rate.txt).  Reported beside the
+# nominal peak, never instead of it.
+SUSTAINED_MFMA_TFLOPS = {"bf16": 1820.0, "f16": 1820.0, "bf16x3": 1820.0}
 PEAK_HBM_GBS = 8000.0                                             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
@@ -170,6 +175,10 @@ def roofline_of(prof, steps, table=None, table_steps=0):
                            "frac": round(ach / PEAK_TFLOPS[m] if hbm_bound else ach_bw / PEAK_HBM_GBS, 4)},
             "mfma_issued_per_product": MFMA_PER_PRODUCT[m],
             "frac_of_mfma_issue_peak": round(ach * MFMA_PER_PRODUCT[m] / PEAK_TFLOPS[m], 4)}
+    if m in SUSTAINED_MFMA_TFLOPS:
+        roof["sustained_mfma_rate"] = {"value": SUSTAINED_MFMA_TFLOPS[m], "unit": "TFLOP/s",
+                                       "frac": round(ach * MFMA_PER_PRODUCT[m] / SUSTAINED_MFMA_TFLOPS[m], 4),
+                                       "source": "tools/ubench/mfma_rate.hip: dense 16x16x32 MFMA stream on all CUs, random operands (profiles/r02_ubench_mfma_rate.txt)"}
     fams = [{"name": e["name"], "ms_per_step": round(e["ms"] / table_steps, 3),
              "tflops": round(e["flops"] / e["ms"] / 1e9, 2) if e["ms"] else 0.0,
              "gbs": round(e["bytes"] / e["ms"] / 1e6, 1) if e["ms"] else 0.0} for e in tab[:8]]

@@ -83,6 +83,7 @@ struct LinGemmParams {
     float* out; unsigned short* out16;          // fp32 and / or bf16 output
     int ldo; long o_seg_stride;
     int act;
+    int xcd_rows;                               // set by the launcher: > 0 = XCD-aware tile order over this many row blocks
 };
 int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st);
 

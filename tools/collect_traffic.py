@@ -22,6 +22,10 @@ def family(kernel_name: str) -> str:
     m = re.search(r"tapgemm_kernel<(\d), (\d+), (\d+), (\d), (\d), (\d+)", kernel_name)
     if m:      # bench.py's family name: tapgemm_<math>_<BM>x<BN>[w8]
         return f"tapgemm_{MATH[m.group(1)]}_{m.group(2)}x{m.group(3)}" + ("w8" if int(m.group(4)) * int(m.group(5)) == 8 else "")
+    if "lingemm_kernel" in kernel_name:
+        return "lingemm_bf16_128x128"
+    if "attention_bf16" in kernel_name:
+        return "attention_bf16"
     m = re.search(r"respair(?:_wide)?_kernel<(\d+)", kernel_name)
     if m:      # bench.py's family name: respair_f16_c<C>
         return f"respair_f16_c{m.group(1)}"

@@ -16,7 +16,9 @@
 //
 // (Measured and rejected: a 256 x 128 tile with eight waves and one workgroup per CU for the large-M convolutions --
 // a quarter fewer operand bytes out of L2 per flop -- ran conv1 / conv2 at 520 / 269 us against 481 / 248: what these
-// GEMMs need is the second resident workgroup, not fewer bytes.)
+// GEMMs need is the second resident workgroup, not fewer bytes.  Operand tiles moved by LDS-DMA (buffer_load_dwordx4 ...
+// lds, swizzle applied on the source side, no staging registers or ds_write: 144 VGPRs instead of 210) gave the same
+// times within 1-2 % on every shape in a same-box A/B -- the VGPR -> LDS store path is not what limits this kernel.)
 //
 // Structure (as respair_wide.hip): one 4-wave workgroup per 128 x 128 tile, two workgroups per CU.  K chunks of 64
 // stream global -> registers -> LDS through a double buffer with the stores spread behind the MFMA blocks; one barrier
@@ -42,6 +44,43 @@ constexpr int LG_ROWB = LG_BK * 2;                                     // 128-by
 constexpr int LG_TILE = LG_BM * LG_ROWB;                               // 16 KB per operand per buffer
 
 __device__ __forceinline__ int lg_swz(int row) { return ((row >> 1) & 3) << 5; }
+
+// accumulators -> fp32 image of the tile in LDS -> bias / GELU / residual -> row-contiguous stores
+__device__ __forceinline__ void lg_epilogue(const LinGemmParams& p, char* smem, const f32x4 (&acc)[4][4], int tid, int wm0, int wn0, int r16, int kg,
+                                            int seg, int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = wm0 + 16 * i + r16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = ((wn0 + 16 * j) >> 2) + kg;                 // 16-byte chunk (4 columns) of the 512-byte image row
+            *reinterpret_cast<f32x4*>(smem + m * 512 + ((co ^ (m & 15)) << 4)) = acc[i][j];
+        }
+    }
+    __syncthreads();
+    const int c4 = tid & 31, er0 = tid >> 5;                           // a lane owns 4 consecutive columns of rows er0 + 8 it
+    const int n = n0 + 4 * c4;
+    const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const long obase = (long)seg * p.o_seg_stride;
+    const bool gelu = p.act == SI_ACT_GELU;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int r = er0 + 8 * it;
+        const int m = m0 + r;
+        if (m >= p.M) break;                                           // rows ascend with `it`
+        const long o = obase + (long)m * p.ldo + n;
+        f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * 512 + ((c4 ^ (r & 15)) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e] + bv[e];
+            if (gelu) x = lg_gelu(x);
+            v[e] = x;
+        }
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
+        if (p.out) *reinterpret_cast<f32x4*>(p.out + o) = v;
+        if (p.out16) *reinterpret_cast<bf16x4*>(p.out16 + o) = __builtin_convertvector(v, bf16x4);
+    }
+}
 
 __global__ __launch_bounds__(LG_NT, 2) void lingemm_kernel(const LinGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][A 128 x 64 | W 128 x 64] bf16 = 64 KB; later the fp32 output image
@@ -163,39 +202,7 @@ __global__ __launch_bounds__(LG_NT, 2) void lingemm_kernel(const LinGemmParams p
         if (c + 1 < nchunks) step(S0{}, c + 1);
     }
 
-    // ---- epilogue: accumulators -> fp32 image of the tile in LDS -> bias / GELU / residual -> row-contiguous stores
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = wm0 + 16 * i + r16;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int co = ((wn0 + 16 * j) >> 2) + kg;                 // 16-byte chunk (4 columns) of the 512-byte image row
-            *reinterpret_cast<f32x4*>(smem + m * 512 + ((co ^ (m & 15)) << 4)) = acc[i][j];
-        }
-    }
-    __syncthreads();
-    const int c4 = tid & 31, er0 = tid >> 5;                           // a lane owns 4 consecutive columns of rows er0 + 8 it
-    const int n = n0 + 4 * c4;
-    const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const long obase = (long)seg * p.o_seg_stride;
-    const bool gelu = p.act == SI_ACT_GELU;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int r = er0 + 8 * it;
-        const int m = m0 + r;
-        if (m >= p.M) break;                                           // rows ascend with `it`
-        const long o = obase + (long)m * p.ldo + n;
-        f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * 512 + ((c4 ^ (r & 15)) << 4));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = v[e] + bv[e];
-            if (gelu) x = lg_gelu(x);
-            v[e] = x;
-        }
-        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
-        if (p.out) *reinterpret_cast<f32x4*>(p.out + o) = v;
-        if (p.out16) *reinterpret_cast<bf16x4*>(p.out16 + o) = __builtin_convertvector(v, bf16x4);
-    }
+    lg_epilogue(p, smem, acc, tid, wm0, wn0, r16, kg, seg, m0, n0);
 }
 
 // SI_OK when launched, negative on error, 1 when the shape is not covered (the caller uses the tap-GEMM).

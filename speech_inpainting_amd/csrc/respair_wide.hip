@@ -46,6 +46,27 @@ __device__ __forceinline__ int swz16(int row) {
     else return ((row >> 1) & 3) << 5;                                // 128-byte rows: two rows per 256-byte bank period
 }
 
+// Diagnostic build only (make timeline; tools/exp_vocoder_only.py): per-phase wall-clock totals of every workgroup's
+// wave 0, in 100 MHz ticks.  [width 0 = C128, 1 = C256][phase]: 0 tile staging, 1 conv-1 slabs, 2 phase-1 epilogue,
+// 3 conv-2 slabs, 4 accumulators -> output image, 5 output pass, 6 tiles, 7 workgroups.
+#ifdef RPW_TIMELINE
+__device__ unsigned long long rpw_tl[2][8];
+#define RPW_TL_DECL unsigned long long tl_t = wall_clock64(); unsigned long long tl_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tl_tiles = 0;
+#define RPW_TL(ph) { const unsigned long long n_ = wall_clock64(); tl_acc[ph] += n_ - tl_t; tl_t = n_; }
+#define RPW_TL_TILE ++tl_tiles;
+#define RPW_TL_FLUSH if (threadIdx.x == 0) { for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&rpw_tl[C == 256][q_], tl_acc[q_]); atomicAdd(&rpw_tl[C == 256][6], tl_tiles); atomicAdd(&rpw_tl[C == 256][7], 1ull); }
+extern "C" int si_debug_rpw_timeline(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rpw_tl), sizeof(rpw_tl)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[2][8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(rpw_tl), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define RPW_TL_DECL
+#define RPW_TL(ph)
+#define RPW_TL_TILE
+#define RPW_TL_FLUSH
+#endif
+
 constexpr int RPW_HALO = 50;                                          // (k - 1) * dil <= 50: k = 11, dil = 5
 
 // ACC: the launch adds into the previous contents of out16 (last pair of the 2nd / 3rd resblock).  Without it the
@@ -91,18 +112,19 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
     const int NS1 = k * NCH, NS = 2 * NS1;
     const int wc = tid % CPRW, wr0 = tid / CPRW;
     u32x4 rw[WSLOTS];
-    auto issueW = [&](int s) {
+    auto issueW1 = [&](int s, int i) {                                 // slot i (rows wr0 + i * WRPP) of slab s
         const bool second = s >= NS1;
         const int q = second ? s - NS1 : s;
         const int tap = q / NCH, ch = q - tap * NCH;
         // readfirstlane: the slab offset is wave-uniform, but the compiler cannot always prove it and would wrap every
         // load in a waterfall loop
         const int soff = __builtin_amdgcn_readfirstlane((tap * C * C + ch * BKW) * 2);
+        const int n = wr0 + i * WRPP;
+        rw[i] = __builtin_amdgcn_raw_buffer_load_b128(second ? w2rsrc : w1rsrc, (n * C + 8 * wc) * 2, soff, 0);
+    };
+    auto issueW = [&](int s) {
 #pragma unroll
-        for (int i = 0; i < WSLOTS; ++i) {
-            const int n = wr0 + i * WRPP;
-            rw[i] = __builtin_amdgcn_raw_buffer_load_b128(second ? w2rsrc : w1rsrc, (n * C + 8 * wc) * 2, soff, 0);
-        }
+        for (int i = 0; i < WSLOTS; ++i) issueW1(s, i);
     };
     auto storeW1 = [&](char* dst, int i) {
         const int n = wr0 + i * WRPP;
@@ -136,6 +158,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
     }
     issueW(0);
     issueY(blockIdx.x);
+    RPW_TL_DECL
 
   for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
     const int nxt = tile + (int)gridDim.x < total ? tile + (int)gridDim.x : tile;   // clamped: the loads below stay unconditional
@@ -162,6 +185,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
         }
     }
     __syncthreads();
+    RPW_TL(0)
 
     f32x4 acc[4][4];                                                   // [time tile i][channel tile j], transposed 16 x 16 tiles
     auto zero_acc = [&]() {
@@ -223,13 +247,19 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
         char* const Wn = Ws + ((s + 1) & 1) * WBYTES;
         static_assert(WSLOTS % KS == 0, "the slab's stores are spread evenly over its k-steps");
         compute(second ? tap : tap * d, ch * (BKW * 2), Ws + (s & 1) * WBYTES, [&](int ks) {
+            // slot by slot: slab s + 1 leaves its register for LDS and the same slot of slab s + 2 is requested into it at
+            // once, so every load has a whole slab of MFMAs to land (steady state: vmcnt(WSLOTS - 1) at each store).
+            // Unconditional (clamped to the last slab): a conditional load drains vmcnt at the join.
+            const int s2 = s + 2 < NS ? s + 2 : NS - 1;
 #pragma unroll
-            for (int i = 0; i < WSLOTS / KS; ++i) storeW1(Wn, ks * (WSLOTS / KS) + i);
-            // unconditional (clamped to the last slab): a conditional load drains vmcnt at the join
-            if (ks == KS - 1) issueW(s + 2 < NS ? s + 2 : NS - 1);
+            for (int i = 0; i < WSLOTS / KS; ++i) {
+                storeW1(Wn, ks * (WSLOTS / KS) + i);
+                issueW1(s2, ks * (WSLOTS / KS) + i);
+            }
         });
         if (s == NS1 - 1) {
             __syncthreads();                                           // every wave has finished reading the activation tile
+            RPW_TL(1)
             // ---- phase-1 epilogue: bias, leaky-ReLU, zero outside the clip, fp16, over the activation tile
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -252,6 +282,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
                 }
             }
             zero_acc();
+            RPW_TL(2)
         }
         if (++ch == NCH) { ch = 0; if (++tap == k) tap = 0; }
         __syncthreads();                                               // slab s + 1 (and, after phase 1, the intermediate) is visible
@@ -261,6 +292,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
     if constexpr (!ACC) issueY(nxt);
     __builtin_amdgcn_sched_barrier(0);
     compute(tap, ch * (BKW * 2), Ws + ((NS - 1) & 1) * WBYTES, [](int) {});
+    RPW_TL(3)
     // the residual / accumulate rows of the output pass travel under the output image's LDS round trip: a lane owns 8
     // consecutive channels of OPASS output rows
     constexpr int ORPP = NT / CPRY;                                    // output rows per pass
@@ -289,6 +321,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
         }
     }
     __syncthreads();
+    RPW_TL(4)
     issueW(0);                                                         // slab 0 of the next tile lands during the output pass
     {
         const f32x4 b2a = *reinterpret_cast<const f32x4*>(Bs + C + 8 * c8), b2b = *reinterpret_cast<const f32x4*>(Bs + C + 8 * c8 + 4);
@@ -314,7 +347,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
     }
     if constexpr (ACC) issueY(nxt);                                    // (no registers to spare earlier in this variant)
     __syncthreads();                                                   // the output image is consumed: the next tile may stage into LDS
+    RPW_TL(5)
+    RPW_TL_TILE
   }
+  RPW_TL_FLUSH
 }
 
 template <int C, int R1, int WARPS_M, int WARPS_N, int BKW>
@@ -327,7 +363,7 @@ static int respair_wide_launch(si_ctx* ctx, const ResPairParams& p0, hipStream_t
     // one persistent workgroup per CU (144-157 KB of LDS each); SI_RP_PERSIST=0 launches one workgroup per tile instead
     static const int persist = getenv("SI_RP_PERSIST") ? atoi(getenv("SI_RP_PERSIST")) : 1;
     const int total = ((p.L + BMo - 1) / BMo) * p.B;
-    const int grid = persist ? std::min(total, si_num_cus(ctx)) : total;
+    const int grid = persist ? std::min(total, si_num_cus(ctx) * (WARPS_M * WARPS_N == 4 ? 2 : 1)) : total;
     char name[48];
     snprintf(name, sizeof(name), "respair_f16_c%d", C);
     const double elems = (double)p.B * p.L * C;
@@ -344,7 +380,8 @@ int si_launch_respair_wide(si_ctx* ctx, int C, const ResPairParams& p, hipStream
     // C = 128: one 8-wave workgroup per CU on 256 rows with whole-tap weight slabs.  (Measured against two 4-wave
     // workgroups per CU on 128 rows / half-tap slabs, which overlap one workgroup's tile load and output pass with the
     // other's MFMAs: 206 / 368 / 515 us per launch for k = 3 / 7 / 11 against 204 / 370 / 576 -- the second form streams
-    // every weight slab twice as often per flop, and weight staging is the loop's largest overhead.)
+    // every weight slab twice as often per flop, and weight staging is the loop's largest overhead.  Measured again on the
+    // persistent form with the slot-by-slot weight prefetch: the two-workgroup form is 10 % slower over the family.)
     if (C == 128) return respair_wide_launch<128, 256, 4, 2, 128>(ctx, p, st);
     if (C == 256) return respair_wide_launch<256, 128, 2, 4, 64>(ctx, p, st);
     return 1;

@@ -14,12 +14,13 @@ for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     w = eng.vocode(mel, stretch=True)
 torch.cuda.synchronize()
 print("ok", float(w.float().abs().mean()))
-if "ablate" in os.environ.get("SI_HIP_LIB", ""):
+if "timeline" in os.environ.get("SI_HIP_LIB", ""):
     import ctypes
-    lib = eng.ctx.lib
-    out = (ctypes.c_ulonglong * 8)()
-    lib.si_debug_rpw_stamps(out, 1)
+    out = (ctypes.c_ulonglong * 16)()
+    eng.ctx.lib.si_debug_rpw_timeline(out, 1)
+    names = ("tile staging", "conv-1 slabs", "phase-1 epilogue", "conv-2 slabs", "acc -> image", "output pass")
     for i, c in enumerate((128, 256)):
-        dt, dr, n, slabs = out[4 * i:4 * i + 4]
-        if n:
-            print(f"C={c}: in-loop clock {dt / dr * 0.1:.3f} GHz; {dt / slabs:.0f} shader cycles per slab ({slabs / n:.1f} slabs per workgroup on average), {n} workgroups")
+        v = out[8 * i:8 * i + 8]
+        tot = sum(v[:6])
+        if tot:
+            print(f"C={c}: {v[6]} tiles on {v[7]} workgroups, {tot / v[6] * 0.01:.2f} us per tile: " + ", ".join(f"{n} {100.0 * x / tot:.1f} %" for n, x in zip(names, v[:6])))

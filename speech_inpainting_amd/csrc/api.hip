@@ -80,6 +80,7 @@ struct si_ctx {
     std::map<const void*, size_t> dyn_lds;   // per kernel: dynamic-LDS limit already raised on this context's device
     // arithmetic-path options, read from the environment when the context is created (all default to 1)
     bool opt_voc_opready = true, opt_voc_res16 = true, opt_enc_opready = true, opt_att_bf16 = true, opt_enc_lingemm = true;
+    int opt_voc_chain = 1;                   // whole-resblock kernel on the C = 32 stage (SI_VOC_CHAIN=0: one launch per conv pair)
     int opt_voc_fuse = 1;                    // 0: never, 1: every covered width, otherwise a mask of the channel counts to fuse (32 | 64 | 128 | 256)
     // constant tables of the mel front-end (built on first use): DFT matrix [Npad][n_fft] = rows cos | -sin, periodic
     // Hann window, transposed Slaney mel basis with the non-zero bin span of every band
@@ -598,6 +599,7 @@ int si_create(si_ctx** out, int device_id, const si_model_desc* desc) {
     ctx->opt_voc_opready = env_flag("SI_VOC_OPREADY");
     ctx->opt_voc_res16 = env_flag("SI_VOC_RES16");
     ctx->opt_voc_fuse = getenv("SI_VOC_FUSE") ? atoi(getenv("SI_VOC_FUSE")) : 1;
+    ctx->opt_voc_chain = getenv("SI_VOC_CHAIN") ? atoi(getenv("SI_VOC_CHAIN")) : 1;
     ctx->opt_enc_opready = env_flag("SI_ENC_OPREADY");
     ctx->opt_att_bf16 = env_flag("SI_ATT_BF16");
     ctx->opt_enc_lingemm = env_flag("SI_ENC_LINGEMM");
@@ -985,6 +987,19 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                 const int rk = d.rb_kernels[j];
                 const float* y = U;
                 const unsigned short* y16 = U16;
+                if (r16 && (fuse_mask & cout) && ctx->opt_voc_chain && d.num_dil == 3) {
+                    // full-rate stage: the whole resblock (three pairs) as one kernel, residual stream in LDS (reschain.hip)
+                    ResChainParams cp{};
+                    cp.y16 = U16; cp.out16 = xs16; cp.B = Bc; cp.L = (int)Lo; cp.k = rk; cp.alpha = 1.0f / nk; cp.accumulate = j > 0;
+                    for (int n = 0; n < 3; ++n) {
+                        const TapGemmParams w1 = gemm_params(ctx, R.c1[n]), w2 = gemm_params(ctx, R.c2[n]);
+                        cp.w1[n] = static_cast<const unsigned short*>(w1.w); cp.w2[n] = static_cast<const unsigned short*>(w2.w);
+                        cp.b1[n] = w1.bias; cp.b2[n] = w2.bias; cp.dil[n] = d.rb_dilations[j][n];
+                    }
+                    const int crc = si_launch_reschain(ctx, cout, cp, st);
+                    if (crc < 0) return crc;
+                    if (crc == 0) continue;
+                }
                 for (int n = 0; n < d.num_dil; ++n) {
                     const int dl = d.rb_dilations[j][n];
                     const bool last_n = (n == d.num_dil - 1);

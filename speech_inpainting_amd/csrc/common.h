@@ -186,6 +186,21 @@ struct ResPairParams {
     int accumulate;              // out += previous out16
 };
 int si_launch_respair_wide(si_ctx* ctx, int C, const ResPairParams& p, hipStream_t st);
+// A whole ResBlock1 -- three (c1, c2) pairs chained, the residual stream kept in LDS -- as one kernel (reschain.hip: C = 32).
+// out = x_3 * alpha [+ previous out]; returns 1 when the shape is not covered.
+struct ResChainParams {
+    const unsigned short* y16;   // [B][L][C] raw fp16 activation stream
+    unsigned short* out16;       // [B][L][C] raw fp16
+    const unsigned short* w1[3]; // per pair: [k][C][C] fp16 (tap, n, ci)
+    const unsigned short* w2[3];
+    const float* b1[3];
+    const float* b2[3];
+    int B, L, k;
+    int dil[3];                  // dilation of c1 per pair (c2 has dilation 1)
+    float alpha;
+    int accumulate;
+};
+int si_launch_reschain(si_ctx* ctx, int C, const ResChainParams& p, hipStream_t st);
 int si_launch_respair(si_ctx* ctx, int C, const unsigned short* y16, unsigned short* out16, const void* w1, const void* w2,
                       const float* b1, const float* b2, int B, int L, int k, int dil, float alpha, int accumulate, hipStream_t st);
 

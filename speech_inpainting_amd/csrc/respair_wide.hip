@@ -90,6 +90,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
     static_assert(C * CPRW % NT == 0 && NT % CPRY == 0 && NT % CPRW == 0, "staging maps");
     static_assert(R1 * ROWBO <= YBYTES + 2 * WBYTES, "the output image reuses the operand region (not the biases behind it)");
 
+    // MODE.FP16_OVFL (hwreg 1, bit 23): a conversion to fp16 that overflows gives +-65504 instead of +-inf, i.e. the
+    // clamp before every rounding comes with the conversion
+    __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Ys = smem;                                             // [R1 + 50][C] fp16: lrelu(y), later t (rows < R1)
     char* const Ws = smem + YBYTES;                                    // [2][C][BKW] fp16 weight slabs
@@ -178,9 +181,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
         const int r = yr0 + i * YRPP;
         if ((i + 1) * YRPP <= R1 || r < R0) {                           // rows < R1 always exist: no branch around their loads
             f16x8 h = __builtin_bit_cast(f16x8, ry[i]);
-            const f16x8 hs = h * (_Float16)0.1f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) h[e] = h[e] > (_Float16)0 ? h[e] : hs[e];
+            h = __builtin_elementwise_max(h, h * (_Float16)0.1f);     // leaky-ReLU(0.1) = max(x, 0.1 x), packed
             *reinterpret_cast<f16x8*>(Ys + r * ROWBY + ((yc << 4) ^ swz16<ROWBY>(r))) = h;
         }
     }
@@ -188,13 +189,16 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
     RPW_TL(0)
 
     f32x4 acc[4][4];                                                   // [time tile i][channel tile j], transposed 16 x 16 tiles
-    auto zero_acc = [&]() {
+    // the accumulators start from the bias of this lane's four consecutive channels: no add per element in the epilogues
+    auto init_acc = [&](const float* bias) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + wn0 + 16 * j + 4 * kg);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i) acc[i][j] = bv;
+        }
     };
-    zero_acc();
+    init_acc(Bs);
     // one slab: acc^T += W[slab] * A[rows + roff][chunk columns]^T.  Fragments are double-buffered in registers: the
     // reads of k-step ks + 1 are issued before the MFMAs of k-step ks, so an MFMA never waits on a read issued just
     // ahead of it.  `hook(ks)` runs behind the MFMAs of k-step ks: the weight-slab stores and the next slab's loads are
@@ -269,19 +273,17 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int n = wn0 + 16 * j + 4 * kg;               // this lane's four consecutive channels
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(Bs + n);
                     f16x4 hv;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][j][e] + bv[e];
-                        v = v > 0.f ? v : 0.1f * v;
-                        v = __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f) * inside;
-                        hv[e] = (_Float16)v;
+                        float v = acc[i][j][e];
+                        v = __builtin_fmaxf(v, 0.1f * v) * inside;
+                        hv[e] = (_Float16)v;                           // saturating (MODE.FP16_OVFL)
                     }
                     *reinterpret_cast<f16x4*>(Ys + m * ROWBY + ((((n >> 3) << 4) ^ swz16<ROWBY>(m)) + 8 * (kg & 1))) = hv;
                 }
             }
-            zero_acc();
+            init_acc(Bs + C);
             RPW_TL(2)
         }
         if (++ch == NCH) { ch = 0; if (++tap == k) tap = 0; }
@@ -324,7 +326,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
     RPW_TL(4)
     issueW(0);                                                         // slab 0 of the next tile lands during the output pass
     {
-        const f32x4 b2a = *reinterpret_cast<const f32x4*>(Bs + C + 8 * c8), b2b = *reinterpret_cast<const f32x4*>(Bs + C + 8 * c8 + 4);
 #pragma unroll
         for (int it = 0; it < OPASS; ++it) {
             const int o = or0 + it * ORPP;
@@ -337,10 +338,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float a = e < 4 ? a0[e] : a1[e - 4];
-                const float bb = e < 4 ? b2a[e] : b2b[e - 4];
-                float v = (a + bb + (float)rh[e]) * p.alpha;
+                float v = (a + (float)rh[e]) * p.alpha;
                 if constexpr (ACC) v += (float)ph[e];
-                out[e] = (_Float16)__builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f);
+                out[e] = (_Float16)v;                                  // saturating (MODE.FP16_OVFL)
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out), orsrc, goff[it], 0, 0);
         }

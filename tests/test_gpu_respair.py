@@ -11,21 +11,63 @@ from tests.common import rms
 pytestmark = pytest.mark.gpu
 
 
-def _engine(varch, gsd, fuse, voc="fp16"):
+def _engine(varch, gsd, fuse, voc="fp16", chain=True):
     from speech_inpainting_amd import synth
     from speech_inpainting_amd.arch import HubertArch
     from speech_inpainting_amd.engine import InpaintingEngine
     harch = HubertArch.tiny()
-    old = os.environ.get("SI_VOC_FUSE")
-    os.environ["SI_VOC_FUSE"] = "1" if fuse else "0"          # read when the context is created
+    want = {"SI_VOC_FUSE": "1" if fuse else "0", "SI_VOC_CHAIN": "1" if chain else "0"}   # read when the context is created
+    old = {k: os.environ.get(k) for k in want}
+    os.environ.update(want)
     try:
         eng = InpaintingEngine(harch, varch, 20, "cuda:0", "fp32", voc)
     finally:
-        if old is None:
-            os.environ.pop("SI_VOC_FUSE", None)
-        else:
-            os.environ["SI_VOC_FUSE"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     return eng.load_state(synth.synth_hubert_state(harch), gsd, synth.synth_codebook(20))
+
+
+@pytest.mark.parametrize("B,Tm", [(3, 57), (2, 1), (1, 130), (5, 9)])
+def test_resblock_chain_kernel_is_bit_identical_to_the_pair_kernels(B, Tm):
+    """reschain.hip (the C = 32 stage's resblock as one kernel) does the pair kernels' arithmetic in the same order: the
+    waveforms must be EQUAL, on clips of several tiles (57 / 130 frames: 14592 / 33280 rows against 648-744 stored rows per
+    tile), clips shorter than one tile (1 frame = 256 rows) and batches that leave workgroups with different tile counts."""
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import VocoderArch
+    varch = VocoderArch.v1()
+    gsd = synth.synth_generator_state(varch)
+    mel = synth.synth_mel(B, Tm, 80, 78)
+    chain = _engine(varch, gsd, True, chain=True).vocode(mel.cuda(), stretch=False).cpu()
+    pairs = _engine(varch, gsd, True, chain=False).vocode(mel.cuda(), stretch=False).cpu()
+    assert chain.shape == pairs.shape == (B, Tm * 256)
+    assert bool(torch.isfinite(chain).all())
+    d = (chain - pairs).abs().max().item()
+    print(f"B={B} Tm={Tm}: max |chain - pairs| = {d:.3e}, signal rms {rms(pairs):.3f}")
+    assert torch.equal(chain, pairs)
+
+
+def test_resblock_chain_kernel_saturates_like_the_pair_kernels():
+    """The tap-GEMM form clamps to +-65504 before every fp16 rounding; the fused kernels set MODE.FP16_OVFL instead, so
+    that the conversion itself saturates.  A mel scaled until the activation stream overflows fp16 must give a finite
+    waveform (an inf anywhere would turn into NaN one convolution later), the same one through the chain and the pair
+    kernels, and close to the clamping form's."""
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import VocoderArch
+    varch = VocoderArch.v1()
+    gsd = synth.synth_generator_state(varch)
+    mel = synth.synth_mel(2, 9, 80, 79) * 3.0e4
+    chain = _engine(varch, gsd, True, chain=True).vocode(mel.cuda(), stretch=False).cpu()
+    pairs = _engine(varch, gsd, True, chain=False).vocode(mel.cuda(), stretch=False).cpu()
+    plain = _engine(varch, gsd, False).vocode(mel.cuda(), stretch=False).cpu()      # tap-GEMM form: explicit clamps
+    assert bool(torch.isfinite(chain).all()) and bool(torch.isfinite(pairs).all()) and bool(torch.isfinite(plain).all())
+    agree = ((chain > 0) == (plain > 0)).float().mean().item()
+    print(f"saturated run: |wave| mean {chain.abs().mean().item():.3f}, max |chain - pairs| {(chain - pairs).abs().max().item():.3e}, "
+          f"sign agreement with the clamping tap-GEMM form {agree:.4f}")
+    assert torch.equal(chain, pairs)
+    assert agree > 0.9
 
 
 @pytest.mark.parametrize("B,Tm", [(3, 57), (2, 5), (1, 130)])

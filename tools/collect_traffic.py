@@ -26,6 +26,8 @@ def family(kernel_name: str) -> str:
         return "lingemm_bf16_128x128"
     if "attention_bf16" in kernel_name:
         return "attention_bf16"
+    if "reschain_kernel" in kernel_name:
+        return "reschain_f16_c32"
     m = re.search(r"respair(?:_wide)?_kernel<(\d+)", kernel_name)
     if m:      # bench.py's family name: respair_f16_c<C>
         return f"respair_f16_c{m.group(1)}"

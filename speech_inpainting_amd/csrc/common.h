@@ -172,6 +172,14 @@ int si_launch_mel_project(si_ctx* ctx, const float* spec, int ld_spec, int nbin,
 int si_launch_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const float* taps, int ntaps, int up, int down,
                             int pre_remove, int n_out, float* y, hipStream_t st);
 
+// leaky-ReLU(0.1) of an accumulator as max(v, 0.1 v) in two VALU ops: fmaxf() would first canonicalise both operands
+// (a v_max_f32 v, v, v each), which nothing downstream of an MFMA accumulator needs
+__device__ __forceinline__ float si_lrelu01(float v) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(0.1f * v));
+    return r;
+}
+
 // One ResBlock1 step y' = (y + conv2(lrelu(conv1(lrelu(y)) + b1)) + b2) * alpha [+ previous y'] as one kernel on the raw
 // fp16 activation stream (respair.hip: C = 32 / 64; respair_wide.hip: C = 128 / 256).  Returns 1 when the shape is not covered.
 struct ResPairParams {

@@ -19,6 +19,14 @@
 // stored: 12-31 % more MFMA work than the pair kernels (18 % at k = 11), a third of their HBM traffic, a ninth of their
 // tile loads, and no fp32 output image at all -- the residual add happens in the accumulator layout against X in LDS.
 //
+// What bounds it (timeline build + tools/ubench/mfma_convloop.hip): with N = 32 a 1 KB activation fragment feeds only two
+// MFMAs, so a tap costs every wave 8 ds_read_b128 per 12 MFMAs; the CU's LDS delivers ~210 B/ns to this access pattern
+// (half of the 256 B/clk table value at the clock the chip holds), which is 13 ns per MFMA and SIMD against 8.7 for the
+// matrix pipe alone -- the tap loop runs at the LDS rate whatever the schedule (fragment double buffer or not, wave
+// priorities, staggered waves: all within 2 %).  The epilogues were bound by 4-way bank conflicts of 8-byte stores in the
+// accumulator layout (16 lanes = one column of 16 rows on 64-byte rows); lanes l and l + 16 now trade halves
+// (v_permlane16_swap) and store whole 16-byte chunks.
+//
 // Arithmetic is exactly that of the pair kernels: the same fp16 operands, taps in the same order into the same fp32
 // accumulators, t and every x_i rounded to fp16 once, (acc + b2 + x) * alpha (+ previous) in fp32 with one rounding --
 // the outputs are bit-identical to three respair launches (tests/test_gpu_respair.py).
@@ -36,20 +44,25 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // Diagnostic build only (make timeline; tools/exp_vocoder_only.py): per-phase wall-clock totals of wave 0 of every
-// workgroup, in 100 MHz ticks: 0 tile staging, 1 c1, 2 c1 epilogue, 3 c2, 4 c2 epilogue, 5 output pass, 6 tiles, 7 workgroups.
+// workgroup, in 100 MHz ticks: 0 tile staging, 1 c1, 2 c1 epilogue, 3 c2, 4 c2 epilogue, 5 output pass, 6 / 7 wave 0's own c2 epilogue / its wait at
+// the barrier that ends it (both included in 4), 8 tiles, 9 workgroups.
 #ifdef RPW_TIMELINE
-__device__ unsigned long long rc_tl[8];
-#define RC_TL_DECL unsigned long long tl_t = wall_clock64(); unsigned long long tl_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tl_tiles = 0;
+__device__ unsigned long long rc_tl[10];
+#define RC_TL_DECL unsigned long long tl_t = wall_clock64(); unsigned long long tl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tl_tiles = 0; unsigned long long tl_w = 0;
+#define RC_TL_W0 tl_w = wall_clock64();
+#define RC_TL_W1(ph) tl_acc[ph] += wall_clock64() - tl_w;
 #define RC_TL(ph) { const unsigned long long n_ = wall_clock64(); tl_acc[ph] += n_ - tl_t; tl_t = n_; }
 #define RC_TL_TILE ++tl_tiles;
-#define RC_TL_FLUSH if (threadIdx.x == 0) { for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&rc_tl[q_], tl_acc[q_]); atomicAdd(&rc_tl[6], tl_tiles); atomicAdd(&rc_tl[7], 1ull); }
+#define RC_TL_FLUSH if (threadIdx.x == 0) { for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&rc_tl[q_], tl_acc[q_]); atomicAdd(&rc_tl[8], tl_tiles); atomicAdd(&rc_tl[9], 1ull); }
 extern "C" int si_debug_rc_timeline(unsigned long long* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rc_tl), sizeof(rc_tl)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(rc_tl), z, sizeof(z)) != hipSuccess) return -1; }
+    if (reset) { unsigned long long z[10] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(rc_tl), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #else
 #define RC_TL_DECL
+#define RC_TL_W0
+#define RC_TL_W1(ph)
 #define RC_TL(ph)
 #define RC_TL_TILE
 #define RC_TL_FLUSH
@@ -174,6 +187,9 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
     // registers (the reads of tap + 1 are issued before the MFMAs of tap; clamped at the end: a harmless re-read)
     auto conv = [&](const char* Wc, int dd) {
         auto load = [&](f16x8 (&y)[RC_RT], f16x8 (&w)[2], int tap) {
+#ifdef RC_ABLATE_READS                                                 // diagnostic build: results are garbage, timing only
+            if (tap > 0) return;
+#endif
             const int soff = (tap - c) * dd * RC_ROWB;
 #pragma unroll
             for (int i = 0; i < RC_RT; ++i) {
@@ -184,6 +200,15 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
             for (int j = 0; j < 2; ++j) w[j] = *reinterpret_cast<const f16x8*>(Wc + tap * (RC_C * RC_ROWB) + preW[j]);
         };
         auto mma = [&](const f16x8 (&y)[RC_RT], const f16x8 (&w)[2]) {
+#ifdef RC_ABLATE_HALF                                                  // diagnostic build: only one wave per SIMD issues MFMAs
+            if (wave >= 4) return;
+#endif
+#ifdef RC_ABLATE_MFMA                                                  // diagnostic build: one MFMA per operand pair keeps the reads alive
+#pragma unroll
+            for (int i = 0; i < RC_RT; ++i) acc[i][0] += __builtin_bit_cast(f32x4, y[i]);
+            acc[0][1] += __builtin_bit_cast(f32x4, w[0]) + __builtin_bit_cast(f32x4, w[1]);
+            return;
+#endif
 #pragma unroll
             for (int i = 0; i < RC_RT; ++i)
 #pragma unroll
@@ -234,53 +259,103 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
 
         // accumulate operand of the last pair, in the accumulator layout (8 bytes per lane); requested before the last c2
         u32x2 prev[ACC ? RC_RT : 1][2];
+        // Epilogue stores.  In the accumulator layout a lane holds 4 channels (8 bytes) of one row and the 16 lanes of a
+        // store group hold the SAME 8-byte column of 16 consecutive rows: on 64-byte rows that is 4 bank slots for 16
+        // lanes, a 4-way conflict on every ds_write_b64 (measured: the epilogues were bound by it).  Lanes l and l + 16
+        // hold the two halves of one 16-byte chunk, so for a PAIR of row tiles (i0, i1) they trade halves
+        // (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second): afterwards a lane with
+        // even k group owns chunk (2 j + kg / 2) of row tile i0, one with odd k group the same chunk of row tile i1 --
+        // half as many stores, 16 bytes each.
+        auto swap_halves = [&](u32x2& p0, u32x2& p1) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const auto r = __builtin_amdgcn_permlane16_swap(p0[q], p1[q], false, false);
+                p0[q] = r[0]; p1[q] = r[1];
+            }
+        };
+        // byte offset of this lane's chunk after the trade, in an image whose row 0 is tile row -`shift`
+        auto chunk_off = [&](int ip, int j, int shift) {
+            const int r = wm0 + 16 * (2 * ip + (kg & 1)) + r16 + shift;
+            return r * RC_ROWB + ((((2 * j + (kg >> 1)) << 4)) ^ rc_swz(r));
+        };
         // c1 epilogue: t = lrelu(acc) (the bias is already in), zero outside the clip, fp16, over A.  The conversions
         // saturate (MODE.FP16_OVFL, set at kernel entry).  MASK only on tiles that reach past the clip.
         auto epi1 = [&](auto maskc) {
             constexpr bool MASK = decltype(maskc)::value;
 #pragma unroll
-            for (int i = 0; i < RC_RT; ++i) {
-                float inside = 1.f;
-                if constexpr (MASK) { const int g = g0 + wm0 + 16 * i + r16; inside = (g >= 0 && g < p.L) ? 1.f : 0.f; }
+            for (int ip = 0; ip < RC_RT / 2; ++ip) {
+                float inside[2] = {1.f, 1.f};
+                if constexpr (MASK) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) { const int g = g0 + wm0 + 16 * (2 * ip + u) + r16; inside[u] = (g >= 0 && g < p.L) ? 1.f : 0.f; }
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    f16x4 hv;
+                    u32x2 pk[2];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][j][e];
-                        v = __builtin_fmaxf(v, 0.1f * v);
-                        if constexpr (MASK) v *= inside;
-                        hv[e] = (_Float16)v;
+                    for (int u = 0; u < 2; ++u) {
+                        f16x4 hv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = si_lrelu01(acc[2 * ip + u][j][e]);
+                            if constexpr (MASK) v *= inside[u];
+                            hv[e] = (_Float16)v;
+                        }
+                        pk[u] = __builtin_bit_cast(u32x2, hv);
                     }
-                    *reinterpret_cast<f16x4*>(As + el_off(i, j, RC_MARG)) = hv;
+                    swap_halves(pk[0], pk[1]);
+                    *reinterpret_cast<u32x4*>(As + chunk_off(ip, j, RC_MARG)) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
                 }
             }
         };
-        // c2 epilogue: x' = (acc + x) * alpha (+ previous), fp16, zero outside the clip; X <- x'; A <- lrelu(x') unless LAST
+        // c2 epilogue: x' = (acc + x) * alpha (+ previous), fp16, zero outside the clip; X <- x'; A <- lrelu(x') unless LAST.
+        // All X reads of a half tile first: the compiler cannot move a read above an earlier X write.
         auto epi2 = [&](auto maskc, auto lastc) {
             constexpr bool MASK = decltype(maskc)::value, LAST = decltype(lastc)::value;
+            constexpr int HP = (RC_RT / 2 + 1) / 2;                     // row-tile pairs per half: 2, then 1
 #pragma unroll
-            for (int i = 0; i < RC_RT; ++i) {
-                _Float16 inside = (_Float16)1.f;
-                if constexpr (MASK) { const int g = g0 + wm0 + 16 * i + r16; inside = (g >= 0 && g < p.L) ? (_Float16)1.f : (_Float16)0.f; }
+            for (int h = 0; h < 2; ++h) {
+                const int ip0 = h * HP, ip1 = h == 0 ? HP : RC_RT / 2;
+                f16x4 xr[HP][2][2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int xo = el_off(i, j, 0);
-                    const f16x4 xr = *reinterpret_cast<const f16x4*>(Xs + xo);
-                    f16x4 xv;
+                for (int ip = ip0; ip < ip1; ++ip)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][j][e] + (float)xr[e];
-                        if constexpr (LAST) {
-                            v *= p.alpha;
-                            if constexpr (ACC) v += (float)__builtin_bit_cast(f16x4, prev[i][j])[e];
-                        }
-                        xv[e] = (_Float16)v;
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) xr[ip - ip0][u][j] = *reinterpret_cast<const f16x4*>(Xs + el_off(2 * ip + u, j, 0));
+#pragma unroll
+                for (int ip = ip0; ip < ip1; ++ip) {
+                    _Float16 inside[2] = {(_Float16)1.f, (_Float16)1.f};
+                    if constexpr (MASK) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) { const int g = g0 + wm0 + 16 * (2 * ip + u) + r16; inside[u] = (g >= 0 && g < p.L) ? (_Float16)1.f : (_Float16)0.f; }
                     }
-                    if constexpr (MASK) xv *= inside;                  // rows outside the clip stay zero for the next convolution
-                    *reinterpret_cast<f16x4*>(Xs + xo) = xv;
-                    if constexpr (!LAST) {
-                        *reinterpret_cast<f16x4*>(As + el_off(i, j, RC_MARG)) = __builtin_elementwise_max(xv, xv * (_Float16)0.1f);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        u32x2 pk[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int i = 2 * ip + u;
+                            f16x4 xv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float v = acc[i][j][e] + (float)xr[ip - ip0][u][j][e];
+                                if constexpr (LAST) {
+                                    v *= p.alpha;
+                                    if constexpr (ACC) v += (float)__builtin_bit_cast(f16x4, prev[i][j])[e];
+                                }
+                                xv[e] = (_Float16)v;
+                            }
+                            if constexpr (MASK) xv *= inside[u];       // rows outside the clip stay zero for the next convolution
+                            pk[u] = __builtin_bit_cast(u32x2, xv);
+                        }
+                        swap_halves(pk[0], pk[1]);
+                        const u32x4 xc = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+                        *reinterpret_cast<u32x4*>(Xs + chunk_off(ip, j, 0)) = xc;
+                        if constexpr (!LAST) {
+                            const f16x8 hx = __builtin_bit_cast(f16x8, xc);
+                            *reinterpret_cast<f16x8*>(As + chunk_off(ip, j, RC_MARG)) = __builtin_elementwise_max(hx, hx * (_Float16)0.1f);
+                        }
                     }
                 }
             }
@@ -318,8 +393,12 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
             issueW(p.w2[LAST ? 0 : pr + 1]);
             __syncthreads();                                           // every wave has finished reading t
             RC_TL(3)
+            RC_TL_W0
             if (edge) epi2(std::true_type{}, lastc); else epi2(std::false_type{}, lastc);
+            RC_TL_W1(6)
+            RC_TL_W0
             __syncthreads();                                           // x' (and W1) are visible
+            RC_TL_W1(7)
             RC_TL(4)
         };
 #pragma unroll 1

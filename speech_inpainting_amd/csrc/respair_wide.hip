@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float v = acc[i][j][e];
-                        v = __builtin_fmaxf(v, 0.1f * v) * inside;
+                        v = si_lrelu01(v) * inside;
                         hv[e] = (_Float16)v;                           // saturating (MODE.FP16_OVFL)
                     }
                     *reinterpret_cast<f16x4*>(Ys + m * ROWBY + ((((n >> 3) << 4) ^ swz16<ROWBY>(m)) + 8 * (kg & 1))) = hv;

@@ -24,9 +24,10 @@ if "timeline" in os.environ.get("SI_HIP_LIB", ""):
         tot = sum(v[:6])
         if tot:
             print(f"C={c}: {v[6]} tiles on {v[7]} workgroups, {tot / v[6] * 0.01:.2f} us per tile: " + ", ".join(f"{n} {100.0 * x / tot:.1f} %" for n, x in zip(names, v[:6])))
-    out = (ctypes.c_ulonglong * 8)()
+    out = (ctypes.c_ulonglong * 10)()
     eng.ctx.lib.si_debug_rc_timeline(out, 1)
     names = ("tile staging", "c1", "c1 epilogue", "c2", "c2 epilogue", "output pass")
     tot = sum(out[:6])
     if tot:
-        print(f"chain C=32: {out[6]} tiles on {out[7]} workgroups, {tot / out[6] * 0.01:.2f} us per tile: " + ", ".join(f"{n} {100.0 * x / tot:.1f} %" for n, x in zip(names, out[:6])))
+        print(f"chain C=32: {out[8]} tiles on {out[9]} workgroups, {tot / out[8] * 0.01:.2f} us per tile: " + ", ".join(f"{n} {100.0 * x / tot:.1f} %" for n, x in zip(names, out[:6]))
+              + f"; of the c2 epilogue, wave 0's own work / its wait at the closing barrier: {100.0 * out[6] / tot:.1f} / {100.0 * out[7] / tot:.1f} %")

@@ -303,56 +303,68 @@ int si_launch_zero_padded_rows(si_ctx* ctx, float* x, int B, int T, int H, const
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
-// One wave per row.  C % 4 == 0, C <= 2048 (the row lives in 8 float4 registers per lane).
+// One wave per row at a time, C % 4 == 0, C <= 2048 (the row lives in 8 float4 registers per lane).  Waves are
+// persistent: wave w walks rows w, w + W, ... and requests its next row before it reduces the current one, so the reads
+// of one row overlap the two reductions and the stores of the previous one (one row per wave and launch had every wave
+// of the chip load, then reduce, then store in step: 16 us for 49 MB).
 template <bool GELU>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ y, unsigned short* __restrict__ y16, long rows, int C,
                                                         float eps) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + row * C;
-    const float* ar = add ? add + row * C : nullptr;
-    f32x4 v[8];
-    float s = 0.f;
+    f32x4 nx[8];
+    auto fetch = [&](long r) {
+        const float* xr = x + r * C;
+        const float* ar = add ? add + r * C : nullptr;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = (j * 64 + lane) * 4;
-        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (i < C) {
-            v[j] = *reinterpret_cast<const f32x4*>(xr + i);
-            if (ar) v[j] += *reinterpret_cast<const f32x4*>(ar + i);
-            s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
-        }
-    }
-    const float mean = wave_sum(s) / C;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = (j * 64 + lane) * 4;
-        if (i < C) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; q += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / C + eps);
-    float* yr = y + row * C;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = (j * 64 + lane) * 4;
-        if (i < C) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i);
-            const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + i);
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = (v[j][e] - mean) * rstd * g[e] + bt[e];
-                o[e] = GELU ? gelu_erf(t) : t;
+        for (int j = 0; j < 8; ++j) {
+            const int i = (j * 64 + lane) * 4;
+            nx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < C) {
+                nx[j] = *reinterpret_cast<const f32x4*>(xr + i);
+                if (ar) nx[j] += *reinterpret_cast<const f32x4*>(ar + i);
             }
-            *reinterpret_cast<f32x4*>(yr + i) = o;
-            // operand-ready copy for a bf16 GEMM consumer (round-to-nearest-even, as the GEMM's own staging would)
-            if (y16) *reinterpret_cast<bf16x4*>(y16 + row * C + i) = __builtin_convertvector(o, bf16x4);
+        }
+    };
+    fetch(row);
+    for (; row < rows; row += nwaves) {
+        f32x4 v[8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = nx[j]; s += v[j][0] + v[j][1] + v[j][2] + v[j][3]; }
+        if (row + nwaves < rows) fetch(row + nwaves);
+        const float mean = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = (j * 64 + lane) * 4;
+            if (i < C) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / C + eps);
+        float* yr = y + row * C;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = (j * 64 + lane) * 4;
+            if (i < C) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i);
+                const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + i);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = (v[j][e] - mean) * rstd * g[e] + bt[e];
+                    o[e] = GELU ? gelu_erf(t) : t;
+                }
+                *reinterpret_cast<f32x4*>(yr + i) = o;
+                // operand-ready copy for a bf16 GEMM consumer (round-to-nearest-even, as the GEMM's own staging would)
+                if (y16) *reinterpret_cast<bf16x4*>(y16 + row * C + i) = __builtin_convertvector(o, bf16x4);
+            }
         }
     }
 }
@@ -361,7 +373,10 @@ int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const flo
                         long rows, int C, float eps, int gelu, hipStream_t st, unsigned short* y16) {
     if (C % 4 != 0 || C > 2048) return si_fail(ctx, SI_EINVAL, "layernorm width %d must be a multiple of 4 and <= 2048", C);
     if (rows <= 0) return SI_OK;
-    dim3 grid((unsigned)((rows + 3) / 4));
+    // 16 waves per CU (four 4-wave workgroups), each walking its share of the rows (same-box A/B over 8 / 16 / 32 waves
+    // per CU and one row per wave: 0.40 / 0.35 / 0.36 / 0.37 ms per step); SI_LN_WAVES overrides the per-CU count
+    static const int per_cu = getenv("SI_LN_WAVES") ? std::max(1, atoi(getenv("SI_LN_WAVES")) / 4) : 4;
+    dim3 grid((unsigned)std::min<long>((rows + 3) / 4, (long)si_num_cus(ctx) * per_cu));
     si_prof_begin(ctx, "layernorm", 8.0 * rows * C, 8.0 * rows * C, st);
     if (gelu) hipLaunchKernelGGL(layernorm_kernel<true>, grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
     else hipLaunchKernelGGL(layernorm_kernel<false>, grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);

@@ -39,6 +39,7 @@ COMBOS = [
     {"SI_ATT_BF16": "0"},                                    # bf16 encoder with the exact-fp32 attention kernel
     {"SI_VOC_RES16": "0", "SI_VOC_OPREADY": "0", "SI_ENC_OPREADY": "0", "SI_ATT_BF16": "0"},   # every non-default arithmetic path at once
     {"SI_ENC_LINGEMM": "0"},                                 # encoder GEMMs on the generic tap-GEMM
+    {"SI_VOC_CHAIN": "0"},                                   # C = 32 stage as one launch per conv pair instead of per resblock
 ]
 
 

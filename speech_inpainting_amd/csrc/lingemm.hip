@@ -20,11 +20,18 @@
 // lds, swizzle applied on the source side, no staging registers or ds_write: 144 VGPRs instead of 210) gave the same
 // times within 1-2 % on every shape in a same-box A/B -- the VGPR -> LDS store path is not what limits this kernel.)
 //
-// Structure (as respair_wide.hip): one 4-wave workgroup per 128 x 128 tile, two workgroups per CU.  K chunks of 64
+// Tile height per shape (same-box, us per launch at B = 32; BM = 128 / 96 / 64): conv1 472 / 521 / 514, conv4 73 / 79 /
+// 69, conv6 24 / 24 / 21, QKV 41 / 46 / 44, out-proj 25 / 21 / 21, FFN1 66 / 71 / 64, FFN2 62 / 53 / 57 -- a shorter tile
+// costs LDS bytes per MFMA but fills the workgroup slots when M = 6368 leaves 300 tall tiles for 512 slots; the
+// launcher's rule (rounds x (BM + 24)) picks 128 / 128 / 64 / 128 / 96 / 64 / 96 for these: 194 -> 174 us per
+// transformer layer.
+//
+// Structure (as respair_wide.hip): one 4-wave workgroup per BM x 128 tile (BM = 128 below), two workgroups per CU.  K chunks of 64
 // stream global -> registers -> LDS through a double buffer with the stores spread behind the MFMA blocks; one barrier
 // per chunk.  Orientation D^T = W * A^T: a lane holds one output row (column l & 15) and four consecutive output
 // columns, so the fp32 output image is written with 16-byte stores.  LDS rows are 128 bytes, chunk c of row r lives at
 // chunk c ^ (((r >> 1) & 3) << 1): conflict-free for the 16x16x32 operand read (see respair_wide.hip).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -39,17 +46,18 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float lg_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-constexpr int LG_BM = 128, LG_BN = 128, LG_BK = 64, LG_NT = 256;
+constexpr int LG_BN = 128, LG_BK = 64, LG_NT = 256;
 constexpr int LG_ROWB = LG_BK * 2;                                     // 128-byte LDS rows
-constexpr int LG_TILE = LG_BM * LG_ROWB;                               // 16 KB per operand per buffer
+constexpr int LG_WTILE = LG_BN * LG_ROWB;                              // 16 KB of weights per buffer
 
 __device__ __forceinline__ int lg_swz(int row) { return ((row >> 1) & 3) << 5; }
 
 // accumulators -> fp32 image of the tile in LDS -> bias / GELU / residual -> row-contiguous stores
-__device__ __forceinline__ void lg_epilogue(const LinGemmParams& p, char* smem, const f32x4 (&acc)[4][4], int tid, int wm0, int wn0, int r16, int kg,
+template <int BM>
+__device__ __forceinline__ void lg_epilogue(const LinGemmParams& p, char* smem, const f32x4 (&acc)[BM / 32][4], int tid, int wm0, int wn0, int r16, int kg,
                                             int seg, int m0, int n0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BM / 32; ++i) {
         const int m = wm0 + 16 * i + r16;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -64,7 +72,7 @@ __device__ __forceinline__ void lg_epilogue(const LinGemmParams& p, char* smem, 
     const long obase = (long)seg * p.o_seg_stride;
     const bool gelu = p.act == SI_ACT_GELU;
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < BM / 8; ++it) {
         const int r = er0 + 8 * it;
         const int m = m0 + r;
         if (m >= p.M) break;                                           // rows ascend with `it`
@@ -82,11 +90,19 @@ __device__ __forceinline__ void lg_epilogue(const LinGemmParams& p, char* smem, 
     }
 }
 
+// BM = rows of the tile (64 / 96 / 128): 2 x 2 waves of (BM / 2) x 64.  The launcher picks BM per shape so that the
+// tiles fill the 2 x CUs workgroup slots in as few, as full rounds as possible (M = 6368 leaves 300 tiles of 128 rows
+// for N = 768: most CUs then run ONE workgroup with nothing to overlap its loads and epilogue with).
+template <int BM>
 __global__ __launch_bounds__(LG_NT, 2) void lingemm_kernel(const LinGemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][A 128 x 64 | W 128 x 64] bf16 = 64 KB; later the fp32 output image
+    constexpr int MT = BM / 32;                                        // 16-row MFMA tiles per wave
+    constexpr int ATILE = BM * LG_ROWB;                                // bytes of the A tile per buffer
+    constexpr int BUF = ATILE + LG_WTILE;
+    constexpr int LG_BM = BM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [2][A BM x 64 | W 128 x 64] bf16; later the fp32 output image
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * 64;
 
     const int ntn = p.N / LG_BN;
     const int mtiles = (p.M + LG_BM - 1) / LG_BM;
@@ -117,46 +133,54 @@ __global__ __launch_bounds__(LG_NT, 2) void lingemm_kernel(const LinGemmParams p
     const int cpt = p.Cin / LG_BK;                                     // K chunks per tap block of the weights
     // two register sets: chunk c + 1 (set (c + 1) & 1) is on its way to LDS while chunk c + 2 is still in flight -- one
     // chunk of MFMAs (~0.5 us) does not cover an L2 round trip under load, two do
-    u32x4 ra[2][4], rw[2][4];
+    u32x4 ra[2][MT], rw[2][4];
     auto issue = [&](auto set, int c) {
         constexpr int S = decltype(set)::value;
         const int tap = c / cpt;
         const int a_soff = __builtin_amdgcn_readfirstlane(c * LG_BK * 2);
         const int w_soff = __builtin_amdgcn_readfirstlane((int)(((long)tap * p.w_tap_stride + (long)(c - tap * cpt) * LG_BK) * 2));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[S][i] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff + i * a_step, a_soff, 0);
-            rw[S][i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff + i * w_step, w_soff, 0);
-        }
+        for (int i = 0; i < MT; ++i) ra[S][i] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff + i * a_step, a_soff, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rw[S][i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff + i * w_step, w_soff, 0);
     };
     const int s_off = sr0 * LG_ROWB + ((sc << 4) ^ lg_swz(sr0));       // rows sr0 + 32 i share the swizzle term of sr0
-    auto store1 = [&](auto set, char* buf, int i) {
+    // staging stores of one chunk in two halves (behind the two MFMA blocks of an iteration)
+    auto store_half = [&](auto set, char* buf, int h) {
         constexpr int S = decltype(set)::value;
-        *reinterpret_cast<u32x4*>(buf + s_off + i * 32 * LG_ROWB) = ra[S][i];
-        *reinterpret_cast<u32x4*>(buf + LG_TILE + s_off + i * 32 * LG_ROWB) = rw[S][i];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            if ((i & 1) == h) *reinterpret_cast<u32x4*>(buf + s_off + i * 32 * LG_ROWB) = ra[S][i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((i & 1) == h) *reinterpret_cast<u32x4*>(buf + ATILE + s_off + i * 32 * LG_ROWB) = rw[S][i];
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int preA[4], preW[4];
+    int preA[MT], preW[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wm0 + 16 * i + r16, n = wn0 + 16 * i + r16;
+    for (int i = 0; i < MT; ++i) {
+        const int r = wm0 + 16 * i + r16;
         preA[i] = r * LG_ROWB + (lg_swz(r) ^ (kg << 4));
-        preW[i] = LG_TILE + n * LG_ROWB + (lg_swz(n) ^ (kg << 4));
     }
-    auto load = [&](bf16x8 (&a)[4], bf16x8 (&w)[4], const char* buf, int ks) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(buf + (preA[i] ^ (ks * 64)));
+    for (int j = 0; j < 4; ++j) {
+        const int n = wn0 + 16 * j + r16;
+        preW[j] = ATILE + n * LG_ROWB + (lg_swz(n) ^ (kg << 4));
+    }
+    auto load = [&](bf16x8 (&a)[MT], bf16x8 (&w)[4], const char* buf, int ks) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(buf + (preA[i] ^ (ks * 64)));
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const bf16x8*>(buf + (preW[j] ^ (ks * 64)));
     };
-    auto mma = [&](const bf16x8 (&a)[4], const bf16x8 (&w)[4]) {
+    auto mma = [&](const bf16x8 (&a)[MT], const bf16x8 (&w)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], a[i], acc[i][j], 0, 0, 0);
     };
@@ -167,17 +191,17 @@ __global__ __launch_bounds__(LG_NT, 2) void lingemm_kernel(const LinGemmParams p
     typedef std::integral_constant<int, 1> S1;
     issue(S0{}, 0);
     issue(S1{}, last < 1 ? last : 1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) store1(S0{}, smem, i);                 // chunk 0; chunk 1 stays in set 1
+    store_half(S0{}, smem, 0);                                         // chunk 0; chunk 1 stays in set 1
+    store_half(S0{}, smem, 1);
     issue(S0{}, last < 2 ? last : 2);
     __syncthreads();
     // Iteration c reads chunk c from LDS buffer c & 1, writes chunk c + 1 (register set (c + 1) & 1, requested two
     // iterations ago) to the other buffer behind the MFMA blocks and requests chunk c + 3 into that same set; loads are
     // unconditional (clamped to the last chunk): a conditional load drains vmcnt at the join.
     auto step = [&](auto land, int c) {
-        const char* buf = smem + (c & 1) * (2 * LG_TILE);
-        char* nxt = smem + ((c + 1) & 1) * (2 * LG_TILE);
-        bf16x8 aa[4], wa[4], ab[4], wb[4];
+        const char* buf = smem + (c & 1) * BUF;
+        char* nxt = smem + ((c + 1) & 1) * BUF;
+        bf16x8 aa[MT], wa[4], ab[MT], wb[4];
         load(aa, wa, buf, 0);
         load(ab, wb, buf, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -185,15 +209,13 @@ __global__ __launch_bounds__(LG_NT, 2) void lingemm_kernel(const LinGemmParams p
         mma(aa, wa);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        store1(land, nxt, 0);                                          // (after the last chunk: a dead buffer)
-        store1(land, nxt, 1);
+        store_half(land, nxt, 0);                                      // (after the last chunk: a dead buffer)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
         mma(ab, wb);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        store1(land, nxt, 2);
-        store1(land, nxt, 3);
+        store_half(land, nxt, 1);
         issue(land, c + 3 < nchunks ? c + 3 : last);
         __syncthreads();
     };
@@ -202,17 +224,14 @@ __global__ __launch_bounds__(LG_NT, 2) void lingemm_kernel(const LinGemmParams p
         if (c + 1 < nchunks) step(S0{}, c + 1);
     }
 
-    lg_epilogue(p, smem, acc, tid, wm0, wn0, r16, kg, seg, m0, n0);
+    lg_epilogue<BM>(p, smem, acc, tid, wm0, wn0, r16, kg, seg, m0, n0);
 }
 
-// SI_OK when launched, negative on error, 1 when the shape is not covered (the caller uses the tap-GEMM).
-int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
-    if (p.N % LG_BN || p.Cin % LG_BK || p.K % LG_BK || p.K != p.ntaps * p.Cin || p.ldo % 4 || p.lda % 8 || p.M <= 0 || p.nseg <= 0) return 1;
-    if (p.x_bytes <= 0 || p.w_bytes <= 0 || (long)p.nseg * p.x_seg_stride * 2 + (long)(p.M + LG_BM) * p.lda * 2 >= (1L << 31)) return 1;
-    if (!p.out && !p.out16) return si_fail(ctx, SI_EINVAL, "lingemm: no output");
-    const size_t lds = 4 * (size_t)LG_TILE;
-    if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(lingemm_kernel), lds)) return rc;
-    const int mtiles = (p.M + LG_BM - 1) / LG_BM;
+template <int BM>
+static int lingemm_launch(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
+    const size_t lds = std::max<size_t>(2 * ((size_t)BM * LG_ROWB + LG_WTILE), (size_t)BM * 512);   // operand double buffer / fp32 output image
+    if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(lingemm_kernel<BM>), lds)) return rc;
+    const int mtiles = (p.M + BM - 1) / BM;
     // XCD-aware tile order when the whole weight matrix sits comfortably in one XCD's 4 MB L2: every row block's A rows
     // are then fetched into one L2 instead of eight.  Same-box A/B: convolutions -4 ... -9 %, out-proj -5 %, QKV -2 %;
     // FFN1 (4.7 MB of weights, 24 column tiles) +9 % -- there the plain order, which keeps 3 of the 24 weight column
@@ -226,8 +245,32 @@ int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     const double outs = (double)p.nseg * p.M * p.N;
     const double bytes = 2.0 * p.nseg * ((double)p.M * p.lda + (p.K - p.lda > 0 ? p.K - p.lda : 0)) + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0)) + 2.0 * p.N * p.K;
     si_prof_begin(ctx, "lingemm_bf16_128x128", 2.0 * macs, bytes, st);
-    hipLaunchKernelGGL(lingemm_kernel, dim3(grid), dim3(LG_NT), lds, st, q);
+    hipLaunchKernelGGL(lingemm_kernel<BM>, dim3(grid), dim3(LG_NT), lds, st, q);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
+}
+
+// SI_OK when launched, negative on error, 1 when the shape is not covered (the caller uses the tap-GEMM).
+int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
+    if (p.N % LG_BN || p.Cin % LG_BK || p.K % LG_BK || p.K != p.ntaps * p.Cin || p.ldo % 4 || p.lda % 8 || p.M <= 0 || p.nseg <= 0) return 1;
+    if (p.x_bytes <= 0 || p.w_bytes <= 0 || (long)p.nseg * p.x_seg_stride * 2 + (long)(p.M + 128) * p.lda * 2 >= (1L << 31)) return 1;
+    if (!p.out && !p.out16) return si_fail(ctx, SI_EINVAL, "lingemm: no output");
+    // Tile height: the workgroup slots are 2 per CU; a launch takes ceil(tiles / slots) rounds of a tile's time, which
+    // grows with BM (plus a fixed part: prologue, epilogue).  Pick the BM with the smallest rounds x (BM + fixed).
+    static const int force = getenv("SI_LG_BM") ? atoi(getenv("SI_LG_BM")) : 0;
+    int bm = 128;
+    if (force == 64 || force == 96 || force == 128) bm = force;
+    else {
+        const long slots = 2L * si_num_cus(ctx);
+        double best = 1e30;
+        for (int cand : {128, 96, 64}) {
+            const long tiles = (long)p.nseg * ((p.M + cand - 1) / cand) * (p.N / LG_BN);
+            const double cost = (double)((tiles + slots - 1) / slots) * (cand + 24);
+            if (cost < best * 0.97) { best = cost; bm = cand; }        // ties and near-ties go to the taller tile
+        }
+    }
+    if (bm == 64) return lingemm_launch<64>(ctx, p, st);
+    if (bm == 96) return lingemm_launch<96>(ctx, p, st);
+    return lingemm_launch<128>(ctx, p, st);
 }

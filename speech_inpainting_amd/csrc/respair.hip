@@ -35,7 +35,9 @@ __device__ __forceinline__ int rpn_swz(int row) {
     else return ((row >> 2) & 1) << 5;                                // 64-byte rows: 4 chunks per row, 4 rows per 256 bytes
 }
 
-template <int C, int R1, int WARPS_M, int TPS>
+// ACC: the launch adds into the previous contents of out16.  Without it the registers of the accumulate rows are free and
+// the NEXT tile's activation rows are requested before the last slab (respair_wide.hip).
+template <int C, int R1, int WARPS_M, int TPS, bool ACC>
 __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairParams p) {
     static_assert(R1 == WARPS_M * 64 && (C == 32 || C == 64), "64-row wave tiles over all C channels");
     constexpr int NT = 64 * WARPS_M;
@@ -67,14 +69,9 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
     const int p1 = d * (k - 1) / 2, p2 = (k - 1) / 2;
     const int BMo = R1 - (k - 1);
     const int R0 = R1 + (k - 1) * d;
-    const int b = blockIdx.y;
-    const int m0 = blockIdx.x * BMo;                                   // first output row of this workgroup
-    const int t_row0 = m0 - p2;                                        // clip row of intermediate row 0
-    const int y_row0 = t_row0 - p1;                                    // clip row of staged activation row 0
-
-    const long seg = (long)b * p.L * C;
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + seg), 0, p.L * C * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out16 + seg, 0, p.L * C * 2, 0x00020000);
+    // ---- persistent workgroups: tile = (clip, row block); a workgroup walks tiles blockIdx.x, + gridDim.x, ...
+    const int tiles_x = (p.L + BMo - 1) / BMo;
+    const int total = tiles_x * p.B;
     const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w1), 0, k * C * C * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w2), 0, k * C * C * 2, 0x00020000);
 
@@ -100,28 +97,45 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
         }
     };
 
+    // the halo'd activation rows of a tile -> registers (rows outside the clip read as zero through the clip's descriptor)
+    const int yc = tid % CPR, yr0 = tid / CPR;
+    u32x4 ry[YSLOTS];
+    auto issueY = [&](int t) {
+        const int tb = t / tiles_x;
+        const int trow0 = (t - tb * tiles_x) * BMo - p2 - p1;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + (long)tb * p.L * C), 0, p.L * C * 2, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < YSLOTS; ++i)
+            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((trow0 + yr0 + i * YRPP) * C + 8 * yc) * 2, 0, 0);
+    };
+
     issueW(0);
+    issueY(blockIdx.x);
     if (tid < C / 2) {                                                 // biases -> LDS: the epilogues read them per lane
         const int which = tid / (C / 4), c4 = (tid % (C / 4)) * 4;
         *reinterpret_cast<f32x4*>(Bs + which * C + c4) = *reinterpret_cast<const f32x4*>((which ? p.b2 : p.b1) + c4);
     }
-    // ---- the activation tile: raw fp16 -> leaky-ReLU(0.1) on the packed halves -> LDS (rows outside the clip read as zero)
-    {
-        const int yc = tid % CPR, yr0 = tid / CPR;
-        u32x4 ry[YSLOTS];
+
+  for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const int nxt = tile + (int)gridDim.x < total ? tile + (int)gridDim.x : tile;   // clamped: the loads below stay unconditional
+    const int b = tile / tiles_x;
+    const int m0 = (tile - b * tiles_x) * BMo;                         // first output row of this tile
+    const int t_row0 = m0 - p2;                                        // clip row of intermediate row 0
+    const long seg = (long)b * p.L * C;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + seg), 0, p.L * C * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out16 + seg, 0, p.L * C * 2, 0x00020000);
+
+    // ---- slab 0 and the activation tile (both requested one tile ago, or at kernel entry) -> LDS: raw fp16 -> leaky-ReLU(0.1)
+    //      on the packed halves (rows outside the clip read as zero)
+    storeW(Ws);
+    issueW(1);                                                         // slab 1 (NS >= 2) goes to the other buffer behind slab 0's MFMAs
 #pragma unroll
-        for (int i = 0; i < YSLOTS; ++i)
-            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, ((y_row0 + yr0 + i * YRPP) * C + 8 * yc) * 2, 0, 0);
-        storeW(Ws);                                                    // slab 0 has landed; the tile is still in flight
-        issueW(1);                                                     // slab 1 (NS >= 2) goes to the other buffer behind slab 0's MFMAs
-#pragma unroll
-        for (int i = 0; i < YSLOTS; ++i) {
-            const int r = yr0 + i * YRPP;
-            if ((i + 1) * YRPP <= R1 || r < R0) {                       // rows < R1 always exist: no branch around their loads
-                f16x8 h = __builtin_bit_cast(f16x8, ry[i]);
-                h = __builtin_elementwise_max(h, h * (_Float16)0.1f); // leaky-ReLU(0.1) = max(x, 0.1 x), packed
-                *reinterpret_cast<f16x8*>(Ys + r * ROWB + ((yc << 4) ^ rpn_swz<ROWB>(r))) = h;
-            }
+    for (int i = 0; i < YSLOTS; ++i) {
+        const int r = yr0 + i * YRPP;
+        if ((i + 1) * YRPP <= R1 || r < R0) {                           // rows < R1 always exist: no branch around their loads
+            f16x8 h = __builtin_bit_cast(f16x8, ry[i]);
+            h = __builtin_elementwise_max(h, h * (_Float16)0.1f);     // leaky-ReLU(0.1) = max(x, 0.1 x), packed
+            *reinterpret_cast<f16x8*>(Ys + r * ROWB + ((yc << 4) ^ rpn_swz<ROWB>(r))) = h;
         }
     }
     __syncthreads();
@@ -191,6 +205,12 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
         const bool second = s >= NS1;
         const int q = second ? s - NS1 : s;
         const int tap0 = q * TPS;
+        if (s == NS - 1) {
+            // last slab: the weight registers are free (slab 0 of the next tile) and, without an accumulate operand, so are
+            // the activation registers: the next tile travels under this slab's MFMAs.  (nxt == tile at the end: harmless.)
+            issueW(0);
+            if constexpr (!ACC) issueY(nxt);
+        }
         compute(tap0, second, min(TPS, k - tap0), Ws + (s & 1) * WBYTES);
         if (s == NS1 - 1) {
             __syncthreads();                                           // every wave has finished reading the activation tile
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
     constexpr int ORPP = NT / CPR;
     constexpr int OPASS = R1 / ORPP;
     const int c8 = tid % CPR, or0 = tid / CPR;
-    u32x4 res[OPASS], prev[OPASS];
+    u32x4 res[OPASS], prev[ACC ? OPASS : 1];
     int goff[OPASS];
 #pragma unroll
     for (int it = 0; it < OPASS; ++it) {
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
         const int grow = m0 + o;
         goff[it] = (o < BMo && grow < p.L) ? (grow * C + 8 * c8) * 2 : (int)0x80000000;
         res[it] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, goff[it], 0, 0);
-        if (p.accumulate) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, goff[it], 0, 0);
+        if constexpr (ACC) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, goff[it], 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -255,31 +275,37 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem + o * ROWBO + (((2 * c8 + 1) ^ (o & OXM)) << 4));
             const f16x8 rh = __builtin_bit_cast(f16x8, res[it]);
             f16x8 ph = {};
-            if (p.accumulate) ph = __builtin_bit_cast(f16x8, prev[it]);
+            if constexpr (ACC) ph = __builtin_bit_cast(f16x8, prev[it]);
             f16x8 out;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float a = e < 4 ? a0[e] : a1[e - 4];
                 float v = (a + (float)rh[e]) * p.alpha;
-                if (p.accumulate) v += (float)ph[e];
+                if constexpr (ACC) v += (float)ph[e];
                 out[e] = (_Float16)v;                                  // saturating (MODE.FP16_OVFL)
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out), orsrc, goff[it], 0, 0);
         }
     }
+    if constexpr (ACC) issueY(nxt);                                    // (no registers to spare earlier in this variant)
+    __syncthreads();                                                   // the output image is consumed: the next tile may stage into LDS
+  }
 }
 
 template <int C, int R1, int WARPS_M, int TPS>
 static int respair_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t st) {
     const int BMo = R1 - (p.k - 1);
     const size_t lds = (size_t)(R1 + RPN_HALO) * C * 2 + 2 * (size_t)TPS * C * C * 2 + 2 * (size_t)C * 4;
-    auto kern = respair_kernel<C, R1, WARPS_M, TPS>;
+    auto kern = p.accumulate ? respair_kernel<C, R1, WARPS_M, TPS, true> : respair_kernel<C, R1, WARPS_M, TPS, false>;
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), lds)) return rc;
+    // persistent workgroups: as many as are resident at once (two per CU for the 4-wave C = 32 form), each walking tiles
+    const int total = ((p.L + BMo - 1) / BMo) * p.B;
+    const int grid = std::min(total, si_num_cus(ctx) * (WARPS_M == 4 ? 2 : 1));
     char name[48];
     snprintf(name, sizeof(name), "respair_f16_c%d", C);
     const double elems = (double)p.B * p.L * C;
     si_prof_begin(ctx, name, 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 2.0 * 2.0 * p.k * C * C, st);
-    hipLaunchKernelGGL(kern, dim3((p.L + BMo - 1) / BMo, p.B), dim3(64 * WARPS_M), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WARPS_M), lds, st, p);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

@@ -21,7 +21,17 @@ __global__ __launch_bounds__(1024) void wave_peak_kernel(const float* __restrict
     const float* x = wav + (size_t)b * N;
     const int s = ms ? ms[b] : 0, e = ms ? me[b] : 0;
     float m = 0.f;
-    for (int i = threadIdx.x; i < N; i += 1024) {
+    // 16 bytes per lane, four loads in flight (one workgroup walks a whole clip); scalar loop for the tail / unaligned clips
+    const bool vec = (N & 3) == 0 && (reinterpret_cast<size_t>(wav) & 15) == 0;
+    const int n4 = vec ? N : 0;
+#pragma unroll 4
+    for (int i = threadIdx.x * 4; i < n4; i += 1024 * 4) {
+        const float4 q = *reinterpret_cast<const float4*>(x + i);
+        const float qe[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) m = fmaxf(m, (i + t >= s && i + t < e) ? 0.f : fabsf(qe[t]));
+    }
+    for (int i = n4 + threadIdx.x; i < N; i += 1024) {
         const float v = (i >= s && i < e) ? 0.f : fabsf(x[i]);
         m = fmaxf(m, v);
     }

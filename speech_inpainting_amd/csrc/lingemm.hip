@@ -244,7 +244,9 @@ static int lingemm_launch(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     const double macs = (double)p.nseg * p.M * p.N * (double)p.K;
     const double outs = (double)p.nseg * p.M * p.N;
     const double bytes = 2.0 * p.nseg * ((double)p.M * p.lda + (p.K - p.lda > 0 ? p.K - p.lda : 0)) + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0)) + 2.0 * p.N * p.K;
-    si_prof_begin(ctx, "lingemm_bf16_128x128", 2.0 * macs, bytes, st);
+    char name[32];
+    snprintf(name, sizeof(name), "lingemm_bf16_%dx128", BM);           // one family per instantiation, as rocprofv3 lists them
+    si_prof_begin(ctx, name, 2.0 * macs, bytes, st);
     hipLaunchKernelGGL(lingemm_kernel<BM>, dim3(grid), dim3(LG_NT), lds, st, q);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());

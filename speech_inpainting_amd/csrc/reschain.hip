@@ -435,7 +435,7 @@ int si_launch_reschain(si_ctx* ctx, int C, const ResChainParams& p, hipStream_t 
     const int total = ((p.L + Rout - 1) / Rout) * p.B;
     const int grid = std::min(total, si_num_cus(ctx));
     const double elems = (double)p.B * p.L * C;
-    si_prof_begin(ctx, "reschain_f16_c32", 3 * 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 3 * 2.0 * 2.0 * p.k * C * C, st);
+    si_prof_begin(ctx, p.accumulate ? "reschain_f16_c32_acc" : "reschain_f16_c32", 3 * 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 3 * 2.0 * 2.0 * p.k * C * C, st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(RC_NT), RC_LDS, st, p);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());

@@ -302,7 +302,7 @@ static int respair_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t st) {
     const int total = ((p.L + BMo - 1) / BMo) * p.B;
     const int grid = std::min(total, si_num_cus(ctx) * (WARPS_M == 4 ? 2 : 1));
     char name[48];
-    snprintf(name, sizeof(name), "respair_f16_c%d", C);
+    snprintf(name, sizeof(name), p.accumulate ? "respair_f16_c%d_acc" : "respair_f16_c%d", C);   // one family per instantiation
     const double elems = (double)p.B * p.L * C;
     si_prof_begin(ctx, name, 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 2.0 * 2.0 * p.k * C * C, st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WARPS_M), lds, st, p);

@@ -365,7 +365,7 @@ static int respair_wide_launch(si_ctx* ctx, const ResPairParams& p0, hipStream_t
     const int total = ((p.L + BMo - 1) / BMo) * p.B;
     const int grid = persist ? std::min(total, si_num_cus(ctx) * (WARPS_M * WARPS_N == 4 ? 2 : 1)) : total;
     char name[48];
-    snprintf(name, sizeof(name), "respair_f16_c%d", C);
+    snprintf(name, sizeof(name), p.accumulate ? "respair_f16_c%d_acc" : "respair_f16_c%d", C);   // one family per instantiation
     const double elems = (double)p.B * p.L * C;
     si_prof_begin(ctx, name, 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 2.0 * 2.0 * p.k * C * C, st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WARPS_M * WARPS_N), lds, st, p);

@@ -121,7 +121,7 @@ def test_lingemm_matches_tapgemm_in_the_bf16_encoder(arch):
         eng.ctx.profile_start(4000)
         outs[flag] = eng.encode(wave).cpu()
         names = {e["name"] for e in eng.ctx.profile_stop()}
-        assert ("lingemm_bf16_128x128" in names) == (flag == "1"), names        # the kernel under test actually ran
+        assert any(n.startswith("lingemm_bf16_") for n in names) == (flag == "1"), names     # the kernel under test actually ran
     ref = InpaintingEngine(harch, varch, 50, "cuda:0", "fp32", "fp32").load_state(hsd, gsd, cb).encode(wave).cpu()
     d = rms(outs["1"], outs["0"]) / rms(outs["0"])
     e1, e0 = rms(outs["1"], ref) / rms(ref), rms(outs["0"], ref) / rms(ref)

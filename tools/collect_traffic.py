@@ -22,15 +22,17 @@ def family(kernel_name: str) -> str:
     m = re.search(r"tapgemm_kernel<(\d), (\d+), (\d+), (\d), (\d), (\d+)", kernel_name)
     if m:      # bench.py's family name: tapgemm_<math>_<BM>x<BN>[w8]
         return f"tapgemm_{MATH[m.group(1)]}_{m.group(2)}x{m.group(3)}" + ("w8" if int(m.group(4)) * int(m.group(5)) == 8 else "")
-    if "lingemm_kernel" in kernel_name:
-        return "lingemm_bf16_128x128"
+    m = re.search(r"lingemm_kernel<(\d+)>", kernel_name)
+    if m:      # bench.py's family name: lingemm_bf16_<BM>x128
+        return f"lingemm_bf16_{m.group(1)}x128"
     if "attention_bf16" in kernel_name:
         return "attention_bf16"
-    if "reschain_kernel" in kernel_name:
-        return "reschain_f16_c32"
-    m = re.search(r"respair(?:_wide)?_kernel<(\d+)", kernel_name)
-    if m:      # bench.py's family name: respair_f16_c<C>
-        return f"respair_f16_c{m.group(1)}"
+    m = re.search(r"reschain_kernel<(\w+)>", kernel_name)
+    if m:      # bench.py's family name: reschain_f16_c32[_acc]
+        return "reschain_f16_c32" + ("_acc" if m.group(1) == "true" else "")
+    m = re.search(r"respair(?:_wide)?_kernel<(\d+),.*?(true|false)>", kernel_name)
+    if m:      # bench.py's family name: respair_f16_c<C>[_acc] (the last template argument is the accumulate variant)
+        return f"respair_f16_c{m.group(1)}" + ("_acc" if m.group(2) == "true" else "")
     return re.sub(r"_kernel.*|\(.*", "", kernel_name).replace("void ", "")
 
 

@@ -13,6 +13,7 @@
  *   si_mel_metrics       <- Metrics.avg_cosine_sim / avg_d2_dist / rmse (row f-4)   I_ea/metrics.py:38-62
  *   si_sisdr             <- Metrics.sisdr (row f-4)                                 I_ea/metrics.py:127-142
  *   si_unit_frontend     <- CodeGenerator.forward's embedding / _upsample / concat front (row f-2)   I_da/src/model.py:79-119,148-189
+ *   si_f0_encoder_forward <- FoVQVAE.encoder(fo) inside CodeGenerator.forward (row f-2)   I_da/src/model.py:160-163 ; I_da/src/modules/jukebox.py:11-116,200-262
  *   si_kmeans_assign     <- kmeans_model.predict(feats) (row f-2)   I_da/scripts/inpainting.py:204-205 ;
  *                           ApplyKmeans.__call__                    I_ea/dataset/km_label.py:20-24
  *   si_resample_poly     <- librosa.load(..., sr=22050 / 16000) resampling (row f-3)   I_ea/predict.py:79-80
@@ -190,13 +191,33 @@ int si_sisdr(si_ctx* ctx, const float* est, const float* ref, int B, int n, floa
  * I_da/configs/LJSpeech/hubert_lut.json): out = concat_channels( emb_c[code], emb_p[f0_code], spk_emb ) with the shorter
  * index series repeated frame-wise up to the longer (`_upsample`, :79-119; the lengths must divide) and the speaker
  * embedding vector repeated over all frames.  code device int64 (B, Fc); f0_code device int64 (B, Fp) or NULL (no pitch
- * part; the indices are what the fixed F0 VQ-VAE emits at :163-165 -- its quantiser is si_kmeans_assign's arg-min, its
- * conv encoder is not part of this library); spk_emb device fp32 (B, E) or NULL; emb_c (Kc, E) / emb_p (Kp, E) device fp32
+ * part; the indices are what the fixed F0 VQ-VAE emits at :163-165 -- its conv encoder is si_f0_encoder_forward, its quantiser
+ * si_kmeans_assign's arg-min); spk_emb device fp32 (B, E) or NULL; emb_c (Kc, E) / emb_p (Kp, E) device fp32
  * tables owned by the caller (they live in the CodeGenerator checkpoint, not in this context).  out device fp32
  * (B, nparts * E, max(Fc, Fp)) channels-first = the input of si_hifigan_forward(stretch = 0) for a generator whose
  * num_mels = nparts * E (384 for hubert_lut.json).  An index outside its table yields NaN.  Needs no weights. */
 int si_unit_frontend(si_ctx* ctx, const int64_t* code, int Fc, const int64_t* f0_code, int Fp, const float* spk_emb,
                      const float* emb_c, int Kc, const float* emb_p, int Kp, int E, int B, float* out, si_stream_t stream);
+
+/* The conv encoder of the fixed F0 VQ-VAE that `CodeGenerator.forward` runs on the F0 track (SURVEY 8(f) row f-2;
+ * I_da/src/model.py:160-163 -> `FoVQVAE.encoder` = I_da/src/modules/jukebox.py `Encoder` :200-262 with one level of
+ * `EncoderConvBlock` :11-116 and `Resnet1D` / `ResConv1DBlock` I_da/src/modules/resnet.py:29-97; configuration
+ * I_da/configs/LJSpeech/hubert_lut.json:42-52): down_t x [Conv1d(k = 2 s (2 s + 1 for odd s), stride s, pad s / 2 (+ 1)) ->
+ * depth x (x + Conv1d_k1(ReLU(Conv1d_k3, dilation growth^j, padding = dilation (ReLU(x)))))] -> Conv1d(width -> out_width, 3, 1, 1).
+ * n_state = int(m_conv * width).  The quantiser behind it (`Bottleneck`, vq.py:117-127: arg-min of |x|^2 - 2 x.k + |k|^2)
+ * is si_kmeans_assign on this function's output rows; the look-up + concat is si_unit_frontend.
+ * weights: device fp32, packed in module order -- per down block: conv weight [width][cin][k], bias [width], then per
+ * res block: k3 weight [n_state][width][3], bias, k1 weight [width][n_state][1], bias; last: weight [out_width][width][3],
+ * bias (si_f0_encoder_weight_floats values).  f0: device fp32 (B, in_width, T).  h_out: device fp32 (B, T', out_width),
+ * CHANNELS-LAST (the (N T, C) rows the bottleneck's `preprocess` builds at vq.py:92-95), T' = si_f0_encoder_frames(T). */
+typedef struct si_f0enc_desc {
+    int32_t in_width, out_width, width, n_state, depth, down_t, stride_t, dilation_growth;
+} si_f0enc_desc;
+size_t si_f0_encoder_weight_floats(const si_f0enc_desc* d);
+int si_f0_encoder_frames(const si_f0enc_desc* d, int T);
+size_t si_f0_encoder_workspace_bytes(const si_f0enc_desc* d, int B, int T);
+int si_f0_encoder_forward(si_ctx* ctx, const si_f0enc_desc* d, const float* weights, const float* f0, int B, int T, float* h_out,
+                          void* workspace, size_t workspace_bytes, si_stream_t stream);
 
 /* Polyphase FIR resampler: the sample-rate conversions in front of the path, `librosa.load(path,
  * sr=22050)` / `sr=16000` at I_ea/predict.py:79-80.  y = upfirdn(taps, x, up, down)[pre_remove : pre_remove + n_out], i.e.

@@ -374,6 +374,38 @@ def code_generator_front(code: torch.Tensor, emb_c: torch.Tensor, f0_code: Optio
     return x
 
 
+def f0_encoder_forward(state: dict, f0: torch.Tensor, down_t: int = 4, stride_t: int = 2, depth: int = 4,
+                       dilation_growth: int = 3) -> torch.Tensor:
+    """f-2.  `FoVQVAE.encoder(fo)` as run inside `CodeGenerator.forward` (I_da/src/model.py:160-163): jukebox.py `Encoder`
+    :200-262 with one level of `EncoderConvBlock` (:11-116): down_t x [Conv1d(k = 2 s, stride s, pad s / 2) (:54-68, odd s:
+    2 s + 1 / s // 2 + 1) -> Resnet1D (resnet.py:57-97): depth x `x + Conv1d_k1(ReLU(Conv1d_k3(ReLU(x), dilation =
+    growth ** j, padding = dilation)))` (:29-54, res_scale 1)] -> Conv1d(width, out, 3, 1, 1) (:80-82).
+    f0 (B, 1, T) -> (B, out_width, T // stride ** down_t).  PARITY UNPINNED: `src.modules` needs no exotic imports, but
+    I_da is outside what may be imported here and the reference holds no fixture; restated from the source text."""
+    pre = "encoder.level_blocks.0.model."
+    k, pad = (2 * stride_t, stride_t // 2) if stride_t % 2 == 0 else (2 * stride_t + 1, stride_t // 2 + 1)
+    x = f0.float()
+    for i in range(down_t):
+        x = F.conv1d(x, state[f"{pre}{i}.0.weight"].float(), state[f"{pre}{i}.0.bias"].float(), stride=stride_t, padding=pad)
+        assert state[f"{pre}{i}.0.weight"].shape[-1] == k
+        for j in range(depth):
+            r = f"{pre}{i}.1.model.{j}.model."
+            dil = dilation_growth ** j
+            y = F.conv1d(F.relu(x), state[r + "1.weight"].float(), state[r + "1.bias"].float(), padding=dil, dilation=dil)
+            x = x + F.conv1d(F.relu(y), state[r + "3.weight"].float(), state[r + "3.bias"].float())
+    return F.conv1d(x, state[f"{pre}{down_t}.weight"].float(), state[f"{pre}{down_t}.bias"].float(), padding=1)
+
+
+def f0_vq_codes(h: torch.Tensor, k: torch.Tensor) -> torch.Tensor:
+    """f-2.  `BottleneckBlock.encode` (I_da/src/modules/vq.py:133-144): h (N, C, T) -> permute / flatten (:92-95) ->
+    arg-min over bins of |x|^2 - 2 x.k^T + |k|^2 (:117-127) -> (N, T) int64.  PARITY UNPINNED (as above)."""
+    n, c, t = h.shape
+    x = h.permute(0, 2, 1).reshape(-1, c).float()
+    kw = k.float().t()
+    dist = (x ** 2).sum(-1, keepdim=True) - 2 * x @ kw + (kw ** 2).sum(0, keepdim=True)
+    return dist.argmin(-1).reshape(n, t)
+
+
 def cos_sim_loss(values: torch.Tensor, labels: torch.Tensor, centroids: torch.Tensor):
     """f-4.  `LossFunction.cos_sim` in full (I_ea/loss_fn.py:29-47): loss = -sum(cos(v, centred target) - 1), pred =
     arg-max labels; plus `cos_sim_target_labels` (:49-62).  values (B, Lm, D), labels (B, Lm) ->

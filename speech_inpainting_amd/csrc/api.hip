@@ -879,6 +879,89 @@ int si_sisdr(si_ctx* ctx, const float* est, const float* ref, int B, int n, floa
     return si_launch_sisdr(ctx, est, ref, B, n, out, static_cast<hipStream_t>(stream));
 }
 
+// ---- F0 VQ-VAE encoder (row f-2): I_da/src/model.py:160-163 runs `self.fo_vqvae.encoder(fo)` -- jukebox.py `Encoder` with one
+//      level = `EncoderConvBlock` (:11-116): down_t x [Conv1d(k = 2 s, stride s, pad s / 2) + Resnet1D(depth blocks of
+//      x + Conv1(ReLU(Conv3_dil(ReLU(x)))), dilation growth^j, resnet.py:29-97)] + Conv1d(width -> out, 3, 1, 1).
+namespace {
+struct F0Shape { int k, pad; };
+F0Shape f0_down_shape(int s) { return (s % 2 == 0) ? F0Shape{2 * s, s / 2} : F0Shape{2 * s + 1, s / 2 + 1}; }   // jukebox.py:54-57
+bool f0_desc_ok(const si_f0enc_desc* d) {
+    return d && d->in_width >= 1 && d->out_width >= 1 && d->width >= 1 && d->n_state >= 1 && d->depth >= 0 && d->down_t >= 1 && d->stride_t >= 1 &&
+           d->dilation_growth >= 1 && d->down_t <= 16 && d->depth <= 32;
+}
+}  // namespace
+
+size_t si_f0_encoder_weight_floats(const si_f0enc_desc* d) {
+    if (!f0_desc_ok(d)) return 0;
+    const F0Shape ds = f0_down_shape(d->stride_t);
+    size_t n = 0;
+    for (int i = 0; i < d->down_t; ++i) {
+        n += (size_t)d->width * (i == 0 ? d->in_width : d->width) * ds.k + d->width;
+        n += (size_t)d->depth * ((size_t)d->n_state * d->width * 3 + d->n_state + (size_t)d->width * d->n_state + d->width);
+    }
+    return n + (size_t)d->out_width * d->width * 3 + d->out_width;
+}
+
+int si_f0_encoder_frames(const si_f0enc_desc* d, int T) {
+    if (!f0_desc_ok(d) || T <= 0) return 0;
+    const F0Shape ds = f0_down_shape(d->stride_t);
+    for (int i = 0; i < d->down_t; ++i) {
+        if (T + 2 * ds.pad < ds.k) return 0;                           // (torch's Conv1d raises: the padded input is shorter than the kernel)
+        T = (T + 2 * ds.pad - ds.k) / d->stride_t + 1;
+    }
+    return T;
+}
+
+size_t si_f0_encoder_workspace_bytes(const si_f0enc_desc* d, int B, int T) {
+    if (!f0_desc_ok(d) || B <= 0 || T <= 0) return 0;
+    const F0Shape ds = f0_down_shape(d->stride_t);
+    const int T1 = (T + 2 * ds.pad - ds.k) / d->stride_t + 1;          // the longest intermediate
+    const size_t c = (size_t)std::max(d->width, d->n_state);
+    return 3 * ((size_t)B * c * std::max(T1, 1) * sizeof(float) + 256);
+}
+
+int si_f0_encoder_forward(si_ctx* ctx, const si_f0enc_desc* d, const float* weights, const float* f0, int B, int T, float* h_out,
+                          void* workspace, size_t workspace_bytes, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!f0_desc_ok(d)) return si_fail(ctx, SI_EINVAL, "si_f0_encoder_forward: bad descriptor");
+    if (!weights || !f0 || !h_out || !workspace || B <= 0 || T <= 0) return si_fail(ctx, SI_EINVAL, "si_f0_encoder_forward: NULL / empty argument");
+    if (si_f0_encoder_frames(d, T) <= 0) return si_fail(ctx, SI_EINVAL, "si_f0_encoder_forward: %d frames are too few for %d stride-%d convolutions", T, d->down_t, d->stride_t);
+    const size_t need = si_f0_encoder_workspace_bytes(d, B, T);
+    if (workspace_bytes < need) return si_fail(ctx, SI_ENOMEM, "workspace of %zu bytes < %zu needed", workspace_bytes, need);
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const F0Shape ds = f0_down_shape(d->stride_t);
+    const size_t slot = need / 3 / sizeof(float);
+    float* buf[3] = {static_cast<float*>(workspace), static_cast<float*>(workspace) + slot, static_cast<float*>(workspace) + 2 * slot};
+    const float* w = weights;
+    const float* x = f0;                                               // (B, in_width, T)
+    int cin = d->in_width, Tc = T, cur = -1;
+    int rc;
+    for (int i = 0; i < d->down_t; ++i) {
+        const int To = (Tc + 2 * ds.pad - ds.k) / d->stride_t + 1;
+        const float* cw = w; w += (size_t)d->width * cin * ds.k;
+        const float* cb = w; w += d->width;
+        const int o = (cur + 1) % 3;
+        if ((rc = si_launch_small_conv1d(ctx, x, cw, cb, nullptr, buf[o], B, cin, Tc, d->width, To, ds.k, d->stride_t, 1, ds.pad, 0, 0, st))) return rc;
+        cur = o; x = buf[cur]; cin = d->width; Tc = To;
+        long dil = 1;
+        for (int j = 0; j < d->depth; ++j) {
+            const float* w3 = w; w += (size_t)d->n_state * d->width * 3;
+            const float* b3 = w; w += d->n_state;
+            const float* w1 = w; w += (size_t)d->width * d->n_state;
+            const float* b1 = w; w += d->width;
+            const int t1 = (cur + 1) % 3, t2 = (cur + 2) % 3;
+            if ((rc = si_launch_small_conv1d(ctx, x, w3, b3, nullptr, buf[t1], B, d->width, Tc, d->n_state, Tc, 3, 1, (int)dil, (int)dil, 1, 0, st))) return rc;
+            if ((rc = si_launch_small_conv1d(ctx, buf[t1], w1, b1, x, buf[t2], B, d->n_state, Tc, d->width, Tc, 1, 1, 1, 0, 1, 0, st))) return rc;
+            cur = t2; x = buf[cur];
+            dil *= d->dilation_growth;
+            if (dil > (1 << 20)) return si_fail(ctx, SI_EINVAL, "si_f0_encoder_forward: dilation overflow");
+        }
+    }
+    const float* fw = w; w += (size_t)d->out_width * d->width * 3;
+    return si_launch_small_conv1d(ctx, x, fw, w, nullptr, h_out, B, d->width, Tc, d->out_width, Tc, 3, 1, 1, 1, 0, 1, st);
+}
+
 int si_unit_frontend(si_ctx* ctx, const int64_t* code, int Fc, const int64_t* f0_code, int Fp, const float* spk_emb, const float* emb_c,
                      int Kc, const float* emb_p, int Kp, int E, int B, float* out, si_stream_t stream) {
     if (!ctx) return SI_EINVAL;

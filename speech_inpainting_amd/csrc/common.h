@@ -220,6 +220,8 @@ int si_launch_respair(si_ctx* ctx, int C, const unsigned short* y16, unsigned sh
 int si_launch_extend_mel(si_ctx* ctx, const float* mel, int B, int D, int Tm, int Tout, int stretch, float* out, int ldo,
                          hipStream_t st);
 // I_da CodeGenerator front (f-2): embedding look-ups + frame repeat + channel concat -> (B, nparts * E, F) channels-first
+int si_launch_small_conv1d(si_ctx* ctx, const float* x, const float* w, const float* bias, const float* res, float* y, int B, int Cin,
+                           int Tin, int Cout, int Tout, int K, int stride, int dil, int pad, int relu_in, int channels_last, hipStream_t st);
 int si_launch_unit_frontend(si_ctx* ctx, const int64_t* code, int Fc, const int64_t* f0_code, int Fp, const float* spk_emb,
                             const float* emb_c, int Kc, const float* emb_p, int Kp, int E, int B, float* out, hipStream_t st);
 // leaky_relu(0.01) -> Conv1d(C -> 1, k, pad k/2) -> tanh ; x (B, L, C) channels-last -> wav (B, L)

@@ -142,3 +142,47 @@ int si_launch_unit_frontend(si_ctx* ctx, const int64_t* code, int Fc, const int6
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ F0 VQ-VAE encoder (row f-2)
+// One Conv1d of the Jukebox-style F0 encoder (I_da/src/modules/jukebox.py:11-116, resnet.py:29-97) on channels-first fp32
+// (B, C, T): y[b][co][t] = bias[co] + sum_ci sum_k w[co][ci][k] * pre(x[b][ci][t * stride + k * dil - pad]) (+ res[b][co][t]),
+// pre = ReLU or identity.  The network is tiny (width 32, 128 at the end; 800 -> 50 frames per 4 s clip): one thread
+// per output element, weights out of L1/L2.  `cl` writes channels-last (B, T, C) -- the rows si_kmeans_assign reads.
+__global__ __launch_bounds__(256) void small_conv1d_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           const float* __restrict__ res, float* __restrict__ y, int B, int Cin, int Tin,
+                                                           int Cout, int Tout, int K, int stride, int dil, int pad, int relu_in, int cl) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * Cout * Tout;
+    if (idx >= total) return;
+    const int t = (int)(idx % Tout);
+    const int co = (int)((idx / Tout) % Cout);
+    const int b = (int)(idx / ((long)Tout * Cout));
+    float acc = bias[co];
+    const float* xb = x + (long)b * Cin * Tin;
+    const float* wc = w + (long)co * Cin * K;
+    for (int ci = 0; ci < Cin; ++ci) {
+        for (int k = 0; k < K; ++k) {
+            const int ti = t * stride + k * dil - pad;
+            if (ti >= 0 && ti < Tin) {
+                float v = xb[(long)ci * Tin + ti];
+                if (relu_in) v = fmaxf(v, 0.f);
+                acc = fmaf(wc[ci * K + k], v, acc);
+            }
+        }
+    }
+    if (res) acc += res[((long)b * Cout + co) * Tout + t];
+    if (cl) y[((long)b * Tout + t) * Cout + co] = acc;
+    else y[((long)b * Cout + co) * Tout + t] = acc;
+}
+
+int si_launch_small_conv1d(si_ctx* ctx, const float* x, const float* w, const float* bias, const float* res, float* y, int B, int Cin,
+                           int Tin, int Cout, int Tout, int K, int stride, int dil, int pad, int relu_in, int channels_last, hipStream_t st) {
+    const long total = (long)B * Cout * Tout;
+    if (total <= 0) return SI_OK;
+    si_prof_begin(ctx, "f0enc_conv1d", 2.0 * total * Cin * K, 4.0 * (total + (double)B * Cin * Tin), st);
+    hipLaunchKernelGGL(small_conv1d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, w, bias, res, y, B, Cin, Tin, Cout,
+                       Tout, K, stride, dil, pad, relu_in, channels_last);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}

@@ -214,14 +214,16 @@ class CodeGenerator:
     units + quantised F0 + speaker embedding -> 384 channels -> the unit HiFi-GAN, upsample rates 5, 4, 4, 2, 2): the
     embedding / `_upsample` / concat front is si_unit_frontend, the generator is the engine's (a VocoderArch with
     num_mels = 3 * embedding_dim).  `emb_c` / `emb_p` are the checkpoint's `emb_c.weight` / `emb_p.weight` tables.
-    The reference quantises F0 with its fixed VQ-VAE inside forward (:160-166); here the caller passes the indices
-    (`f0_code`), e.g. from `InpaintingEngine.ctx.kmeans_assign` on the encoder's output against the VQ codebook."""
+    The reference quantises F0 with its fixed VQ-VAE inside forward (:160-166): pass `f0_quantizer=F0Quantizer(engine,
+    fo_vqvae_state)` and call with `f0=`; or pass the indices directly as `f0_code=`."""
 
-    def __init__(self, engine: InpaintingEngine, emb_c: torch.Tensor, emb_p: Optional[torch.Tensor] = None):
+    def __init__(self, engine: InpaintingEngine, emb_c: torch.Tensor, emb_p: Optional[torch.Tensor] = None,
+                 f0_quantizer: Optional["F0Quantizer"] = None):
         self.engine = engine
         dev = engine.device
         self.emb_c = emb_c.to(dev, torch.float32).contiguous()
         self.emb_p = None if emb_p is None else emb_p.to(dev, torch.float32).contiguous()
+        self.f0_quantizer = f0_quantizer                               # `self.fo_vqvae` of the reference (:63-71)
 
     def eval(self):
         return self
@@ -230,11 +232,16 @@ class CodeGenerator:
         return None
 
     def __call__(self, **kwargs) -> torch.Tensor:
-        """code (B, Frame) int64; f0_code (B, Frame_p) int64 (optional); emb (B, Emb) speaker embedding (optional)
-        -> (B, 1, Frame * hop) waveform."""
+        """code (B, Frame) int64; f0 (B, 1, Frame_f0) fp32 as in the reference (quantised here by the fixed F0 VQ-VAE when
+        the generator was built with an `F0Quantizer`) or f0_code (B, Frame_p) int64 directly; emb (B, Emb) speaker
+        embedding (optional) -> (B, 1, Frame * hop) waveform."""
         dev = self.engine.device
         code = kwargs["code"].to(dev, torch.int64).contiguous()
         f0c = kwargs.get("f0_code")
+        if f0c is None and kwargs.get("f0") is not None:
+            if self.f0_quantizer is None:
+                raise ValueError("CodeGenerator: an F0 track needs the F0 VQ-VAE (pass f0_quantizer=F0Quantizer(...)) or f0_code")
+            f0c = self.f0_quantizer(kwargs["f0"])
         emb = kwargs.get("emb")
         x = self.engine.ctx.unit_frontend(code, self.emb_c,
                                           None if f0c is None else f0c.to(dev, torch.int64).contiguous(), self.emb_p,
@@ -242,6 +249,46 @@ class CodeGenerator:
         return self.engine.vocode(x, stretch=False).unsqueeze(1)
 
     forward = __call__
+
+
+class F0Quantizer:
+    """The fixed F0 VQ-VAE front that `CodeGenerator.forward` runs on the F0 track (I_da/src/model.py:160-163):
+    `z_p = fo_vqvae.vq(fo_vqvae.encoder(fo))[0][0]` -- jukebox.py `Encoder` (one level) on the GPU (si_f0_encoder_forward),
+    then the bottleneck's nearest-codebook arg-min (vq.py:117-127; si_kmeans_assign).  `state` is the `FoVQVAE`
+    state dict (`encoder.level_blocks.0.model...`, `vq.level_blocks.0.k`)."""
+
+    def __init__(self, engine: InpaintingEngine, state: dict, desc: Optional["native.F0EncDesc"] = None):
+        from . import native
+        self.engine = engine
+        self.desc = desc or native.F0EncDesc()
+        dev = engine.device
+        self.weights = pack_f0_encoder(state, self.desc).to(dev)
+        self.codebook = state["vq.level_blocks.0.k"].to(dev, torch.float32).contiguous()
+
+    def features(self, f0: torch.Tensor) -> torch.Tensor:
+        """f0 (B, 1, T) -> (B, T', 128) encoder output, channels-last."""
+        return self.engine.ctx.f0_encoder(self.desc, self.weights, f0.to(self.engine.device, torch.float32).contiguous())
+
+    def __call__(self, f0: torch.Tensor) -> torch.Tensor:
+        """f0 (B, 1, T) -> z_p (B, T') int64, the indices `emb_p` is looked up with."""
+        h = self.features(f0)
+        B, Tp, E = h.shape
+        return self.engine.ctx.kmeans_assign(h.reshape(B * Tp, E), self.codebook).reshape(B, Tp)
+
+
+def pack_f0_encoder(state: dict, desc) -> torch.Tensor:
+    """Flatten the encoder's parameters in module order (the order si_f0_encoder_forward consumes them):
+    `encoder.level_blocks.0.model.<i>.0` = strided conv, `.model.<i>.1.model.<j>.model.1` / `.model.3` = the res block's
+    k3 / k1 convs (resnet.py:37-42), `.model.<down_t>` = the last conv (jukebox.py:80-82)."""
+    pre = "encoder.level_blocks.0.model."
+    parts = []
+    for i in range(desc.down_t):
+        parts += [state[f"{pre}{i}.0.weight"], state[f"{pre}{i}.0.bias"]]
+        for j in range(desc.depth):
+            r = f"{pre}{i}.1.model.{j}.model."
+            parts += [state[r + "1.weight"], state[r + "1.bias"], state[r + "3.weight"], state[r + "3.bias"]]
+    parts += [state[f"{pre}{desc.down_t}.weight"], state[f"{pre}{desc.down_t}.bias"]]
+    return torch.cat([p.detach().to(torch.float32).reshape(-1) for p in parts]).contiguous()
 
 
 class Metrics:

@@ -22,9 +22,32 @@ SI_MAX_CONV, SI_MAX_UPS, SI_MAX_RB, SI_MAX_DIL = 8, 8, 4, 4
 
 EXPORTS = ["si_version", "si_create", "si_destroy", "si_last_error", "si_load_weights", "si_alloc_weights",
            "si_weights_device_ptr", "si_workspace_bytes", "si_hubert_forward", "si_hubert_forward_padded", "si_codebook_splice",
-           "si_codebook_splice_labels", "si_codebook_metrics", "si_kmeans_assign", "si_mel_metrics", "si_sisdr", "si_unit_frontend", "si_resample_poly", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
+           "si_codebook_splice_labels", "si_codebook_metrics", "si_kmeans_assign", "si_mel_metrics", "si_sisdr", "si_unit_frontend",
+           "si_f0_encoder_weight_floats", "si_f0_encoder_frames", "si_f0_encoder_workspace_bytes", "si_f0_encoder_forward",
+           "si_resample_poly", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
            "si_vocoder_samples", "si_profile_start", "si_profile_filter", "si_profile_stop",
            "si_debug_capture", "si_debug_size"]
+
+
+class _F0EncStruct(C.Structure):
+    """Mirror of si_f0enc_desc."""
+    _fields_ = [(n, C.c_int32) for n in ("in_width", "out_width", "width", "n_state", "depth", "down_t", "stride_t", "dilation_growth")]
+
+
+class F0EncDesc:
+    """`f0_encoder_params` of I_da/configs/LJSpeech/hubert_lut.json:42-52 (one level): n_state = int(m_conv * width)."""
+
+    def __init__(self, in_width=1, out_width=128, width=32, depth=4, down_t=4, stride_t=2, dilation_growth=3, m_conv=1.0):
+        self.in_width, self.out_width, self.width, self.depth = int(in_width), int(out_width), int(width), int(depth)
+        self.down_t, self.stride_t, self.dilation_growth = int(down_t), int(stride_t), int(dilation_growth)
+        self.n_state = int(m_conv * width)
+
+    def as_struct(self) -> _F0EncStruct:
+        return _F0EncStruct(self.in_width, self.out_width, self.width, self.n_state, self.depth, self.down_t, self.stride_t, self.dilation_growth)
+
+    def down_kernel(self):
+        s = self.stride_t
+        return (2 * s, s // 2) if s % 2 == 0 else (2 * s + 1, s // 2 + 1)          # jukebox.py:54-57
 
 
 class ProfileEntry(C.Structure):
@@ -128,6 +151,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.si_mel_metrics.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.si_sisdr.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.si_unit_frontend.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, vp, vp]
+    lib.si_f0_encoder_weight_floats.argtypes = [vp]
+    lib.si_f0_encoder_weight_floats.restype = C.c_size_t
+    lib.si_f0_encoder_frames.argtypes = [vp, i32]
+    lib.si_f0_encoder_frames.restype = i32
+    lib.si_f0_encoder_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.si_f0_encoder_workspace_bytes.restype = C.c_size_t
+    lib.si_f0_encoder_forward.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, C.c_size_t, vp]
     lib.si_resample_poly.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.si_hifigan_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_mel_frames.argtypes = [i32]
@@ -350,6 +380,25 @@ class NativeContext:
         out = torch.empty(B, nparts * E, max(Fc, Fp), dtype=torch.float32, device=self.device)
         self._check(self.lib.si_unit_frontend(self._h, _ptr(code), Fc, _ptr(f0_code), Fp, _ptr(spk_emb), _ptr(emb_c), Kc, _ptr(emb_p), Kp,
                                               E, B, _ptr(out), self._stream()), "si_unit_frontend")
+        return out
+
+    def f0_encoder(self, desc: "F0EncDesc", weights: torch.Tensor, f0: torch.Tensor) -> torch.Tensor:
+        """f0 (B, in_width, T) fp32, weights = the packed encoder parameters (see include/si_hip.h) -> (B, T', out_width)
+        fp32 channels-last: the rows the VQ bottleneck quantises (I_da/src/model.py:160-163)."""
+        assert f0.is_cuda and f0.dtype == torch.float32 and f0.dim() == 3 and f0.is_contiguous() and f0.shape[1] == desc.in_width
+        assert weights.is_cuda and weights.dtype == torch.float32 and weights.dim() == 1 and weights.is_contiguous()
+        d = desc.as_struct()
+        need = int(self.lib.si_f0_encoder_weight_floats(C.byref(d)))
+        if weights.numel() != need:
+            raise ValueError(f"F0 encoder weights: {weights.numel()} floats, the descriptor needs {need}")
+        B, _, T = f0.shape
+        Tp = int(self.lib.si_f0_encoder_frames(C.byref(d), T))
+        if Tp <= 0:
+            raise ValueError(f"{T} F0 frames are too few for this encoder")
+        ws = torch.empty(int(self.lib.si_f0_encoder_workspace_bytes(C.byref(d), B, T)), dtype=torch.uint8, device=self.device)
+        out = torch.empty(B, Tp, desc.out_width, dtype=torch.float32, device=self.device)
+        self._check(self.lib.si_f0_encoder_forward(self._h, C.byref(d), _ptr(weights), _ptr(f0), B, T, _ptr(out), _ptr(ws), ws.numel(),
+                                                   self._stream()), "si_f0_encoder_forward")
         return out
 
     def resample_poly(self, x: torch.Tensor, taps: torch.Tensor, up: int, down: int, pre_remove: int, n_out: int) -> torch.Tensor:

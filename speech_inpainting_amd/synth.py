@@ -183,3 +183,25 @@ def synth_mask_frames(batch: int, num_frames: int, mask_frames: int, seed: int =
     lo = min(int(0.5 * frame_rate), max(num_frames - mask_frames - 1, 0))
     hi = max(num_frames - mask_frames - int(0.7 * frame_rate), lo + 1)
     return torch.randint(lo, hi, (batch,), generator=g, dtype=torch.int32)
+
+
+def synth_f0_vqvae_state(desc, l_bins: int = 20, seed: int = 11) -> dict:
+    """Random parameters with the names and shapes of the `FoVQVAE` checkpoint's encoder + bottleneck
+    (I_da/src/model.py:16-21, jukebox.py:11-116, resnet.py:29-97, vq.py:15-22)."""
+    g = torch.Generator().manual_seed(seed)
+    k, _ = desc.down_kernel()
+    sd = {}
+    pre = "encoder.level_blocks.0.model."
+
+    def conv(name, cout, cin, kk):
+        sd[name + ".weight"] = torch.randn(cout, cin, kk, generator=g) * (1.0 / (cin * kk) ** 0.5)
+        sd[name + ".bias"] = torch.randn(cout, generator=g) * 0.1
+
+    for i in range(desc.down_t):
+        conv(f"{pre}{i}.0", desc.width, desc.in_width if i == 0 else desc.width, k)
+        for j in range(desc.depth):
+            conv(f"{pre}{i}.1.model.{j}.model.1", desc.n_state, desc.width, 3)
+            conv(f"{pre}{i}.1.model.{j}.model.3", desc.width, desc.n_state, 1)
+    conv(f"{pre}{desc.down_t}", desc.out_width, desc.width, 3)
+    sd["vq.level_blocks.0.k"] = torch.randn(l_bins, desc.out_width, generator=g)
+    return sd

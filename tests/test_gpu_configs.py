@@ -215,3 +215,55 @@ def test_ida_code_generator_front_and_decoder_match_oracle():
     err, sig = rms(wav, ref), rms(ref)
     print(f"CodeGenerator (LUT): waveform rms error {err:.3e} (signal rms {sig:.3f})")
     assert err <= 1e-4 * max(sig, 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(3, 800), (1, 64), (2, 1000)])
+def test_f0_vqvae_front_matches_oracle(B, T):
+    """Row f-2, the F0 side of `CodeGenerator.forward` (I_da/src/model.py:160-166): the fixed VQ-VAE's conv encoder
+    (si_f0_encoder_forward: 4 x [stride-2 conv + 4 dilated res blocks] + conv, hubert_lut.json:42-52), its bottleneck's
+    arg-min (si_kmeans_assign) and the embedding look-up -- against the oracle's restatement of jukebox.py / resnet.py /
+    vq.py (parity unpinned: I_da is not importable).  fp32 MACs in a different order: 1e-5 relative; codes equal wherever
+    the two nearest bins are not within rounding of each other."""
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import native, synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import F0Quantizer, InpaintingEngine
+    harch, varch = HubertArch.tiny(), VocoderArch.v1()
+    eng = InpaintingEngine(harch, varch, 20, "cuda:0", "fp32", "fp32").load_state(synth.synth_hubert_state(harch), synth.synth_generator_state(varch),
+                                                                                    synth.synth_codebook(20))
+    desc = native.F0EncDesc()
+    sd = synth.synth_f0_vqvae_state(desc, l_bins=20, seed=5)
+    g = torch.Generator().manual_seed(T)
+    f0 = torch.randn(B, 1, T, generator=g).abs() * 2.0                 # a normalised, non-negative F0 track
+    f0[:, :, T // 3: T // 2] = 0.0                                     # with an unvoiced stretch
+    h_ref = R.f0_encoder_forward(sd, f0)                               # (B, 128, T / 16)
+    q = F0Quantizer(eng, sd, desc)
+    h = q.features(f0.cuda()).cpu()                                    # (B, T / 16, 128) channels-last
+    assert h.shape == (B, T // 16, 128) and h_ref.shape == (B, 128, T // 16)
+    rel = rms(h, h_ref.transpose(1, 2)) / rms(h_ref)
+    print(f"B={B} T={T}: encoder output rms {rms(h_ref):.3f}, relative error {rel:.2e}")
+    assert rel <= 1e-5
+    z = q(f0.cuda()).cpu()
+    z_ref = R.f0_vq_codes(h_ref, sd["vq.level_blocks.0.k"])
+    assert z.shape == z_ref.shape == (B, T // 16) and z.dtype == torch.int64
+    # where they differ the two bins must be a near-tie for the oracle's own distances
+    x = h_ref.permute(0, 2, 1).reshape(-1, 128)
+    d = ((x[:, None, :] - sd["vq.level_blocks.0.k"][None]) ** 2).sum(-1)
+    dz, dr = d.gather(1, z.reshape(-1, 1)), d.gather(1, z_ref.reshape(-1, 1))
+    assert bool(((dz - dr).abs() <= 1e-4 * dr.abs() + 1e-6).all())
+    assert (z == z_ref).float().mean().item() >= 0.99
+    # through the module wrapper, as the reference calls it: generator(code=..., f0=..., emb=...)
+    from speech_inpainting_amd.engine import CodeGenerator
+    E = 128
+    emb_c, emb_p = torch.randn(100, E, generator=g) * 0.5, torch.randn(20, E, generator=g) * 0.5
+    code = torch.randint(0, 100, (B, T // 16), generator=g)
+    gen = CodeGenerator(eng, emb_c, emb_p, f0_quantizer=q)
+    x_a = eng.ctx.unit_frontend(code.cuda(), gen.emb_c, z.cuda(), gen.emb_p, None)
+    x_b = eng.ctx.unit_frontend(code.cuda(), gen.emb_c, q(f0.cuda()), gen.emb_p, None)
+    assert torch.equal(x_a, x_b) and x_a.shape == (B, 2 * E, T // 16)
+    # wrong weight count / too few frames are refused
+    with pytest.raises(ValueError):
+        eng.ctx.f0_encoder(desc, q.weights[:-1].contiguous(), f0.cuda())
+    with pytest.raises(ValueError):
+        eng.ctx.f0_encoder(desc, q.weights, f0[:, :, :8].contiguous().cuda())

@@ -110,3 +110,21 @@ def test_padded_batches_match_reference_goldens():
         with torch.no_grad():
             nomask = R.custom_model_forward(hsd, harch, x)
         assert float((nomask[1] - ref[1]).pow(2).mean().sqrt()) > 1e-3
+
+
+def test_f0_encoder_restatement_shapes_and_known_answer():
+    """The oracle's F0 VQ-VAE encoder (row f-2, parity unpinned) against a direct evaluation of its definition on a
+    hand-checkable case: all-zero convolution weights leave only the biases, so every res block adds its k1 bias and
+    the last conv returns its bias; and T frames come out as T // 16."""
+    import torch
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import native, synth
+    desc = native.F0EncDesc()
+    sd = synth.synth_f0_vqvae_state(desc, seed=2)
+    assert R.f0_encoder_forward(sd, torch.randn(2, 1, 320)).shape == (2, 128, 20)
+    z = {k: (torch.zeros_like(v) if k.endswith("weight") else v) for k, v in sd.items()}
+    out = R.f0_encoder_forward(z, torch.randn(1, 1, 64))
+    last = z["encoder.level_blocks.0.model.4.bias"]
+    assert torch.allclose(out, last[None, :, None].expand_as(out))
+    codes = R.f0_vq_codes(torch.randn(2, 128, 5), sd["vq.level_blocks.0.k"])
+    assert codes.shape == (2, 5) and int(codes.min()) >= 0 and int(codes.max()) < 20

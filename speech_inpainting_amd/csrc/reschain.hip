@@ -28,7 +28,7 @@
 // (v_permlane16_swap) and store whole 16-byte chunks.
 //
 // Arithmetic is exactly that of the pair kernels: the same fp16 operands, taps in the same order into the same fp32
-// accumulators, t and every x_i rounded to fp16 once, (acc + b2 + x) * alpha (+ previous) in fp32 with one rounding --
+// accumulators (started from the bias), t and every x_i rounded to fp16 once, (acc + x) * alpha (+ previous) in fp32 with one rounding --
 // the outputs are bit-identical to three respair launches (tests/test_gpu_respair.py).
 #include <algorithm>
 #include <cstdio>

@@ -13,7 +13,8 @@
 //   * LDS rows are 64 / 128 bytes: the chunk swizzle term of a row keeps chunk bit 0 (see swz16 in respair_wide.hip) and
 //     spreads the 2 or 4 rows of a 256-byte bank period.
 // Arithmetic is that of the two-launch tap-GEMM form in the same mode: fp16 operands, fp32 accumulate, the intermediate
-// rounded to fp16 once, (acc + b2 + y) * alpha (+ previous) in fp32, one rounding on store.
+// rounded to fp16 once, (acc + y) * alpha (+ previous) in fp32 with the accumulators started from the bias, one
+// saturating rounding on store.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>

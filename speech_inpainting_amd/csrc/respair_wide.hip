@@ -12,7 +12,7 @@
 //             to fp16 and written OVER the activation tile (dead once conv1 is done)
 //   phase 2   acc[R1 rows] = conv2(t); rows >= R1 - (k-1) are recomputed by the neighbouring tile
 //   epilogue  the fp32 accumulators go through an LDS image of the output tile (everything else is dead), then
-//             out = (acc + b2 + y) * alpha (+ previous out) is computed and stored row-contiguously: 16 bytes per lane,
+//             out = (acc + y) * alpha (+ previous out) (the accumulators start from b2) is computed and stored row-contiguously: 16 bytes per lane,
 //             whole 256 / 512-byte rows per wave instruction, residual / accumulate reads in the same shape
 // Weight slabs ([C n][BKW ci] of one tap: 32 KB) stream L2 -> registers -> LDS through a double buffer, one workgroup
 // barrier per slab; a slab feeds 32 (C = 128) / 16 (C = 256) MFMAs per wave, against 8 per barrier in the tap-GEMM.

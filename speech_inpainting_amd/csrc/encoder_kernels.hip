@@ -669,26 +669,32 @@ __global__ __launch_bounds__(256) void attention_bf16in_kernel(const unsigned sh
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float mrun = -INFINITY, lrun = 0.f;
 
+    // The next key tile is requested while the current one is computed on (one tile = 4 + 4 MFMAs per wave: a load issued
+    // and consumed inside the same trip left the whole L2 round trip exposed, seven times per launch).  Rows past the
+    // clip are clamped to its last row: they are masked below (key >= Tk) or belong to query rows that are not stored.
+    const int kr = tid >> 3, kj = tid & 7;                             // K tile: 32 rows x 128 bytes, one 16-byte chunk per thread
+    const int vrp = tid >> 4, vj = tid & 15;                           // V: two consecutive keys x four dims per thread
+    u32x4_t kv;
+    u32x2_t w0, w1;
+    auto fetch = [&](int k0) {
+        kv = *reinterpret_cast<const u32x4_t*>(base + (long)min(k0 + kr, T - 1) * ld + H + 8 * kj);
+        w0 = *reinterpret_cast<const u32x2_t*>(base + (long)min(k0 + 2 * vrp, T - 1) * ld + 2 * H + 4 * vj);
+        w1 = *reinterpret_cast<const u32x2_t*>(base + (long)min(k0 + 2 * vrp + 1, T - 1) * ld + 2 * H + 4 * vj);
+    };
+    fetch(0);
     for (int k0 = 0; k0 < Tk; k0 += ATT_KT) {
         __syncthreads();
-        {   // K tile: 32 rows x 128 bytes, one 16-byte chunk per thread
-            const int r = tid >> 3, j = tid & 7;
-            u32x4_t kv = {0u, 0u, 0u, 0u};
-            if (k0 + r < T) kv = *reinterpret_cast<const u32x4_t*>(base + (long)(k0 + r) * ld + H + 8 * j);
-            *reinterpret_cast<u32x4_t*>(Ks + r * ATB_LDK + 8 * j) = kv;
-        }
-        {   // V transposed: a thread takes two consecutive keys x four dims and writes four packed 32-bit words
-            const int rp = tid >> 4, j = tid & 15;
-            u32x2_t w0 = {0u, 0u}, w1 = {0u, 0u};
-            if (k0 + 2 * rp < T) w0 = *reinterpret_cast<const u32x2_t*>(base + (long)(k0 + 2 * rp) * ld + 2 * H + 4 * j);
-            if (k0 + 2 * rp + 1 < T) w1 = *reinterpret_cast<const u32x2_t*>(base + (long)(k0 + 2 * rp + 1) * ld + 2 * H + 4 * j);
+        *reinterpret_cast<u32x4_t*>(Ks + kr * ATB_LDK + 8 * kj) = kv;
+        {   // V transposed: four packed 32-bit words (key pair) per thread
+            const bool in0 = k0 + 2 * vrp < T, in1 = k0 + 2 * vrp + 1 < T;     // zero, not a clamped copy: P * V must not see NaN payloads of stale rows
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const unsigned lo = (w0[e >> 1] >> (16 * (e & 1))) & 0xffffu, hi = (w1[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-                *reinterpret_cast<unsigned*>(Vt + (4 * j + e) * ATB_LDV + 2 * rp) = lo | (hi << 16);
+                const unsigned lo = in0 ? (w0[e >> 1] >> (16 * (e & 1))) & 0xffffu : 0u, hi = in1 ? (w1[e >> 1] >> (16 * (e & 1))) & 0xffffu : 0u;
+                *reinterpret_cast<unsigned*>(Vt + (4 * vj + e) * ATB_LDV + 2 * vrp) = lo | (hi << 16);
             }
         }
         __syncthreads();
+        fetch(k0 + ATT_KT < Tk ? k0 + ATT_KT : k0);                   // unconditional (clamped): a conditional load drains vmcnt at the join
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;

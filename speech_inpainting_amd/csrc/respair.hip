@@ -152,7 +152,9 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
         }
     };
     init_acc(Bs);
-    int preW[TN];
+    int lin0[4], preW[TN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lin0[i] = (wm0 + 16 * i + r16) * ROWB + (kg << 4);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = 16 * j + r16;
@@ -164,11 +166,14 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
         const int nsteps = ntap * KS;
         auto load = [&](f16x8 (&y)[4], f16x8 (&w)[TN], int q) {
             const int tl = KS == 1 ? q : q >> 1, ks = KS == 1 ? 0 : q & 1;
-            const int roff = second ? tap0 + tl : (tap0 + tl) * d;
+            // linear byte offset of (row, k group) plus the step's scalar part, then the swizzle as an XOR of address bits
+            // (row bits 1-2 -> byte bits 5-6 on 128-byte rows, row bit 2 -> byte bit 5 on 64-byte rows): 3 VALU ops per read
+            // instead of 6 -- the VALU shares the SIMD's issue port with the MFMAs (C = 64: -4 % same-box)
+            const int soff = (second ? tap0 + tl : (tap0 + tl) * d) * ROWB + ks * 64;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int r = wm0 + 16 * i + r16 + roff;
-                y[i] = *reinterpret_cast<const f16x8*>(Ys + r * ROWB + ((rpn_swz<ROWB>(r) ^ (kg << 4)) ^ (ks * 64)));
+                const int lin = lin0[i] + soff;
+                y[i] = *reinterpret_cast<const f16x8*>(Ys + (lin ^ ((lin >> 3) & (ROWB == 128 ? 0x60 : 0x20))));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) w[j] = *reinterpret_cast<const f16x8*>(Wc + tl * (C * ROWB) + (preW[j] ^ (ks * 64)));

@@ -48,15 +48,19 @@ int si_launch_extend_mel(si_ctx* ctx, const float* mel, int B, int D, int Tm, in
     return SI_OK;
 }
 
-// 256 output samples per workgroup; the (256 + k - 1) x C input rows are staged (with the leaky-relu applied)
-// into LDS with an odd row stride so the per-lane row walks are bank-conflict free.
+// 256 output samples per workgroup; the (256 + k - 1) x C input rows are staged (with the leaky-relu applied) into LDS as
+// fp32 rows of C + 4 floats: 16-byte aligned, so a lane walks its rows with ds_read_b128, and for C = 32 the 36-dword
+// stride puts the 16 lanes of every ds_read_b128 group on 16 different 4-bank slots (one lane = one output sample = one
+// row per tap).  The kernel is bound by these reads (7 x 128 bytes per output sample): as 4-byte reads on a 33-float
+// stride it took 114 us per 32 clips, three times the HBM time of its input.
 // x16 (optional): the input as raw fp16 (the vocoder's fp16 activation stream) instead of fp32 x
 __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const unsigned short* __restrict__ x16,
                                                         const float* __restrict__ w, const float* __restrict__ bias, int L, int C,
                                                         int k, float* __restrict__ wav) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xs = reinterpret_cast<float*>(smem);              // [(256 + k - 1)][C + 1]
-    float* ws = xs + (256 + k - 1) * (C + 1);                // [k][C]
+    const int ldx = C + 4;
+    float* xs = reinterpret_cast<float*>(smem);              // [(256 + k - 1)][C + 4]
+    float* ws = xs + (256 + k - 1) * ldx;                    // [k][C]
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * 256;
     const int pad = k / 2;
@@ -72,7 +76,8 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
             else v = *reinterpret_cast<const f32x4*>(x + xoff + (long)t * C + 4 * j);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xs[r * (C + 1) + 4 * j + e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+        *reinterpret_cast<f32x4*>(xs + r * ldx + 4 * j) = v;
     }
     for (int idx = threadIdx.x; idx < k * C; idx += 256) ws[idx] = w[idx];
     __syncthreads();
@@ -80,9 +85,13 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     if (t >= L) return;
     float acc = bias[0];
     for (int kk = 0; kk < k; ++kk) {
-        const float* xr = xs + (threadIdx.x + kk) * (C + 1);
+        const float* xr = xs + (threadIdx.x + kk) * ldx;
         const float* wr = ws + kk * C;
-        for (int c = 0; c < C; ++c) acc = fmaf(xr[c], wr[c], acc);
+        for (int c = 0; c < C; c += 4) {                     // the same fma order as a scalar walk over c
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c), wv = *reinterpret_cast<const f32x4*>(wr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = fmaf(xv[e], wv[e], acc);
+        }
     }
     wav[(long)b * L + t] = tanhf(acc);
 }
@@ -91,7 +100,7 @@ int si_launch_conv_post(si_ctx* ctx, const float* x, const float* w, const float
                         hipStream_t st, const unsigned short* x16) {
     if (C % 4 != 0) return si_fail(ctx, SI_EINVAL, "conv_post: C=%d must be a multiple of 4", C);
     if (B <= 0 || L <= 0) return SI_OK;
-    const size_t lds = ((size_t)(256 + k - 1) * (C + 1) + (size_t)k * C) * sizeof(float);
+    const size_t lds = ((size_t)(256 + k - 1) * (C + 4) + (size_t)k * C) * sizeof(float);
     if (lds > 160 * 1024) return si_fail(ctx, SI_EINVAL, "conv_post: %d channels x %d taps need %zu bytes of LDS (> 160 KiB)", C, k, lds);
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(conv_post_kernel), lds)) return rc;
     dim3 grid((L + 255) / 256, B);

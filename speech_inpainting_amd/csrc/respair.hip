@@ -23,6 +23,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -220,23 +221,35 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
         compute(tap0, second, min(TPS, k - tap0), Ws + (s & 1) * WBYTES);
         if (s == NS1 - 1) {
             __syncthreads();                                           // every wave has finished reading the activation tile
-            // ---- phase-1 epilogue: bias, leaky-ReLU, zero outside the clip, fp16, over the activation tile
+            // ---- phase-1 epilogue: leaky-ReLU (the bias is in the accumulators), zero outside the clip, fp16, over the activation
+            //      tile, as 16-byte stores after lanes l and l + 16 traded chunk halves (respair_wide.hip, reschain.hip: the
+            //      8-byte stores of the accumulator layout are 4-way bank conflicted on these rows)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = wm0 + 16 * i + r16;
-                const int grow = t_row0 + m;
-                const float inside = (grow >= 0 && grow < p.L) ? 1.f : 0.f;    // as a factor: no branch per element
+            for (int ip = 0; ip < 2; ++ip) {
+                float inside[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int grow = t_row0 + wm0 + 16 * (2 * ip + u) + r16;
+                    inside[u] = (grow >= 0 && grow < p.L) ? 1.f : 0.f;         // as a factor: no branch per element
+                }
+                const int ms = wm0 + 16 * (2 * ip + (kg & 1)) + r16;           // the row this lane stores after the trade
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int n = 16 * j + 4 * kg;                     // this lane's four consecutive channels
-                    f16x4 hv;
+                    u32x2 pk[2];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][j][e];
-                        v = si_lrelu01(v) * inside;
-                        hv[e] = (_Float16)v;                           // saturating (MODE.FP16_OVFL)
+                    for (int u = 0; u < 2; ++u) {
+                        f16x4 hv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(si_lrelu01(acc[2 * ip + u][j][e]) * inside[u]);   // saturating (MODE.FP16_OVFL)
+                        pk[u] = __builtin_bit_cast(u32x2, hv);
                     }
-                    *reinterpret_cast<f16x4*>(Ys + m * ROWB + ((((n >> 3) << 4) ^ rpn_swz<ROWB>(m)) + 8 * (kg & 1))) = hv;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const auto r = __builtin_amdgcn_permlane16_swap(pk[0][q], pk[1][q], false, false);
+                        pk[0][q] = r[0]; pk[1][q] = r[1];
+                    }
+                    const int ch = 2 * j + (kg >> 1);                          // 16-byte chunk (8 channels) of the row
+                    *reinterpret_cast<u32x4*>(Ys + ms * ROWB + ((ch << 4) ^ rpn_swz<ROWB>(ms))) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
                 }
             }
             init_acc(Bs + C);

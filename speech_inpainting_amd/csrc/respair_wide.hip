@@ -33,6 +33,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -264,23 +265,38 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
         if (s == NS1 - 1) {
             __syncthreads();                                           // every wave has finished reading the activation tile
             RPW_TL(1)
-            // ---- phase-1 epilogue: bias, leaky-ReLU, zero outside the clip, fp16, over the activation tile
+            // ---- phase-1 epilogue: leaky-ReLU (the bias is in the accumulators), zero outside the clip, fp16, over the activation
+            //      tile.  In the accumulator layout the 16 lanes of a store group hold one 8-byte column of 16 consecutive rows:
+            //      a 4-way bank conflict per ds_write_b64 on these rows.  Lanes l and l + 16 hold the two halves of a 16-byte
+            //      chunk, so for a pair of row tiles they trade halves (v_permlane16_swap: odd 16-lane rows of the first operand
+            //      <-> even rows of the second): a lane with even k group then owns chunk (n / 8) of row tile 2 ip, one with
+            //      odd k group the same chunk of row tile 2 ip + 1 -- half as many stores, 16 bytes each (reschain.hip).
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = wm0 + 16 * i + r16;
-                const int grow = t_row0 + m;
-                const float inside = (grow >= 0 && grow < p.L) ? 1.f : 0.f;    // as a factor: no branch per element
+            for (int ip = 0; ip < 2; ++ip) {
+                float inside[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int grow = t_row0 + wm0 + 16 * (2 * ip + u) + r16;
+                    inside[u] = (grow >= 0 && grow < p.L) ? 1.f : 0.f;         // as a factor: no branch per element
+                }
+                const int ms = wm0 + 16 * (2 * ip + (kg & 1)) + r16;           // the row this lane stores after the trade
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int n = wn0 + 16 * j + 4 * kg;               // this lane's four consecutive channels
-                    f16x4 hv;
+                    u32x2 pk[2];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][j][e];
-                        v = si_lrelu01(v) * inside;
-                        hv[e] = (_Float16)v;                           // saturating (MODE.FP16_OVFL)
+                    for (int u = 0; u < 2; ++u) {
+                        f16x4 hv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(si_lrelu01(acc[2 * ip + u][j][e]) * inside[u]);   // saturating (MODE.FP16_OVFL)
+                        pk[u] = __builtin_bit_cast(u32x2, hv);
                     }
-                    *reinterpret_cast<f16x4*>(Ys + m * ROWBY + ((((n >> 3) << 4) ^ swz16<ROWBY>(m)) + 8 * (kg & 1))) = hv;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const auto r = __builtin_amdgcn_permlane16_swap(pk[0][q], pk[1][q], false, false);
+                        pk[0][q] = r[0]; pk[1][q] = r[1];
+                    }
+                    const int ch = ((wn0 + 16 * j) >> 3) + (kg >> 1);          // 16-byte chunk (8 channels) of the row
+                    *reinterpret_cast<u32x4*>(Ys + ms * ROWBY + ((ch << 4) ^ swz16<ROWBY>(ms))) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
                 }
             }
             init_acc(Bs + C);

@@ -49,20 +49,25 @@ __device__ __forceinline__ int swz16(int row) {
 
 // Diagnostic build only (make timeline; tools/exp_vocoder_only.py): per-phase wall-clock totals of every workgroup's
 // wave 0, in 100 MHz ticks.  [width 0 = C128, 1 = C256][phase]: 0 tile staging, 1 conv-1 slabs, 2 phase-1 epilogue,
-// 3 conv-2 slabs, 4 accumulators -> output image, 5 output pass, 6 tiles, 7 workgroups.
+// 3 conv-2 slabs, 4 accumulators -> output image, 5 output pass, 6 tiles, 7 workgroups, 8 / 9: of phase 4, wave 0's wait at the
+// barrier behind the last slab / its image stores.
 #ifdef RPW_TIMELINE
-__device__ unsigned long long rpw_tl[2][8];
-#define RPW_TL_DECL unsigned long long tl_t = wall_clock64(); unsigned long long tl_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tl_tiles = 0;
+__device__ unsigned long long rpw_tl[2][10];
+#define RPW_TL_DECL unsigned long long tl_t = wall_clock64(); unsigned long long tl_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tl_tiles = 0; unsigned long long tl_w = 0, tl_sub[2] = {0, 0};
+#define RPW_TL_W0 tl_w = wall_clock64();
+#define RPW_TL_W1(q) tl_sub[q] += wall_clock64() - tl_w;
 #define RPW_TL(ph) { const unsigned long long n_ = wall_clock64(); tl_acc[ph] += n_ - tl_t; tl_t = n_; }
 #define RPW_TL_TILE ++tl_tiles;
-#define RPW_TL_FLUSH if (threadIdx.x == 0) { for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&rpw_tl[C == 256][q_], tl_acc[q_]); atomicAdd(&rpw_tl[C == 256][6], tl_tiles); atomicAdd(&rpw_tl[C == 256][7], 1ull); }
+#define RPW_TL_FLUSH if (threadIdx.x == 0) { for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&rpw_tl[C == 256][q_], tl_acc[q_]); atomicAdd(&rpw_tl[C == 256][6], tl_tiles); atomicAdd(&rpw_tl[C == 256][7], 1ull); atomicAdd(&rpw_tl[C == 256][8], tl_sub[0]); atomicAdd(&rpw_tl[C == 256][9], tl_sub[1]); }
 extern "C" int si_debug_rpw_timeline(unsigned long long* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rpw_tl), sizeof(rpw_tl)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[2][8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(rpw_tl), z, sizeof(z)) != hipSuccess) return -1; }
+    if (reset) { unsigned long long z[2][10] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(rpw_tl), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #else
 #define RPW_TL_DECL
+#define RPW_TL_W0
+#define RPW_TL_W1(q)
 #define RPW_TL(ph)
 #define RPW_TL_TILE
 #define RPW_TL_FLUSH
@@ -326,7 +331,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
         res[it] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, goff[it], 0, 0);
         if constexpr (ACC) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, goff[it], 0, 0);
     }
+    RPW_TL_W0
     __syncthreads();                                                   // every wave is done with the operand tiles
+    RPW_TL_W1(0)
+    RPW_TL_W0
 
     // ---- final epilogue: accumulators -> fp32 image of the output tile in LDS -> row-contiguous residual add + store
 #pragma unroll
@@ -338,6 +346,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
             *reinterpret_cast<f32x4*>(smem + m * ROWBO + ((co ^ (m & 15)) << 4)) = acc[i][j];
         }
     }
+    RPW_TL_W1(1)
     __syncthreads();
     RPW_TL(4)
     issueW(0);                                                         // slab 0 of the next tile lands during the output pass

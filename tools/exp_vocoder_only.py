@@ -16,14 +16,15 @@ torch.cuda.synchronize()
 print("ok", float(w.float().abs().mean()))
 if "timeline" in os.environ.get("SI_HIP_LIB", ""):
     import ctypes
-    out = (ctypes.c_ulonglong * 16)()
+    out = (ctypes.c_ulonglong * 20)()
     eng.ctx.lib.si_debug_rpw_timeline(out, 1)
     names = ("tile staging", "conv-1 slabs", "phase-1 epilogue", "conv-2 slabs", "acc -> image", "output pass")
     for i, c in enumerate((128, 256)):
-        v = out[8 * i:8 * i + 8]
+        v = out[10 * i:10 * i + 10]
         tot = sum(v[:6])
         if tot:
-            print(f"C={c}: {v[6]} tiles on {v[7]} workgroups, {tot / v[6] * 0.01:.2f} us per tile: " + ", ".join(f"{n} {100.0 * x / tot:.1f} %" for n, x in zip(names, v[:6])))
+            print(f"C={c}: {v[6]} tiles on {v[7]} workgroups, {tot / v[6] * 0.01:.2f} us per tile: " + ", ".join(f"{n} {100.0 * x / tot:.1f} %" for n, x in zip(names, v[:6]))
+                  + f"; of acc -> image: wave 0 waiting behind the last slab {100.0 * v[8] / tot:.1f} %, its image stores {100.0 * v[9] / tot:.1f} %")
     out = (ctypes.c_ulonglong * 10)()
     eng.ctx.lib.si_debug_rc_timeline(out, 1)
     names = ("tile staging", "c1", "c1 epilogue", "c2", "c2 epilogue", "output pass")

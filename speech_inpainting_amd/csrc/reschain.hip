@@ -83,8 +83,9 @@ constexpr int RC_WSLOTS = (RC_WBYTES / 16 + RC_NT - 1) / RC_NT;       // 3
 constexpr int RC_YSLOTS = RC_R * 4 / RC_NT;                           // 6
 static_assert(RC_R * 4 % RC_NT == 0, "tile staging map");
 
-// 64-byte rows: chunk bit 0 is left alone, the other bit spreads the 4 rows of a 256-byte bank period (respair.hip)
-__device__ __forceinline__ int rc_swz(int row) { return ((row >> 2) & 1) << 5; }
+// 64-byte rows: chunk c of row r lives at chunk c ^ ((r >> 1) & 3) -- conflict-free for the 16x16x32 operand read at any
+// first row AND for the epilogues' 16-byte stores of 8 consecutive rows (rpn_swz in respair.hip)
+__device__ __forceinline__ int rc_swz(int row) { return ((row >> 1) & 3) << 4; }
 
 }  // namespace
 
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
         for (int i = 0; i < RC_RT; ++i) { acc[i][0] = b0; acc[i][1] = b1v; }
     };
     // Operand addresses: linear byte offset of (row, k group) plus the tap's row offset (a scalar), then the swizzle as an
-    // XOR of address bits: bit 8 (row bit 2) -> bit 5.  Three VALU ops per fragment read.
+    // XOR of address bits: bits 7-8 (row bits 1-2) -> bits 4-5.  Three VALU ops per fragment read.
     int lin0[RC_RT];
 #pragma unroll
     for (int i = 0; i < RC_RT; ++i) lin0[i] = (wm0 + 16 * i + r16 + RC_MARG) * RC_ROWB + (kg << 4);
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
 #pragma unroll
             for (int i = 0; i < RC_RT; ++i) {
                 const int lin = lin0[i] + soff;
-                y[i] = *reinterpret_cast<const f16x8*>(As + (lin ^ ((lin >> 3) & 32)));
+                y[i] = *reinterpret_cast<const f16x8*>(As + (lin ^ ((lin >> 3) & 0x30)));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) w[j] = *reinterpret_cast<const f16x8*>(Wc + tap * (RC_C * RC_ROWB) + preW[j]);

@@ -29,12 +29,15 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int RPN_HALO = 50;                                          // (k - 1) * dil <= 50: k = 11, dil = 5
 
-// (chunk XOR term of a row) << 4 for 64- and 128-byte rows: chunk bit 0 is left alone (the two halves of a ds_read_b128
-// lane group of the 16x16x32 operand read differ in exactly that bit), the other bits spread the rows of a bank period
+// (chunk XOR term of a row) << 4 for 64- and 128-byte rows: chunk c of row r lives at chunk c ^ ((r >> 1) & 3) (64-byte rows:
+// 4 chunks) / c ^ (r & 7) (128-byte rows: 8 chunks).  Checked by enumeration over the hardware's lane groups: the
+// 16x16x32 operand read (ds_read_b128) is conflict-free for ANY first row, so are the staging stores, and so are the
+// epilogue's 16-byte stores of 8 consecutive rows to one logical chunk (the first swizzle of this round kept chunk bit 0
+// fixed and left those 2-way conflicted).
 template <int ROWB>
 __device__ __forceinline__ int rpn_swz(int row) {
-    if constexpr (ROWB == 128) return ((row >> 1) & 3) << 5;          // 8 chunks per row, 2 rows per 256 bytes
-    else return ((row >> 2) & 1) << 5;                                // 64-byte rows: 4 chunks per row, 4 rows per 256 bytes
+    if constexpr (ROWB == 128) return (row & 7) << 4;
+    else return ((row >> 1) & 3) << 4;
 }
 
 // ACC: the launch adds into the previous contents of out16.  Without it the registers of the accumulate rows are free and
@@ -168,13 +171,13 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
         auto load = [&](f16x8 (&y)[4], f16x8 (&w)[TN], int q) {
             const int tl = KS == 1 ? q : q >> 1, ks = KS == 1 ? 0 : q & 1;
             // linear byte offset of (row, k group) plus the step's scalar part, then the swizzle as an XOR of address bits
-            // (row bits 1-2 -> byte bits 5-6 on 128-byte rows, row bit 2 -> byte bit 5 on 64-byte rows): 3 VALU ops per read
+            // (row bits 0-2 -> byte bits 4-6 on 128-byte rows, row bits 1-2 -> byte bits 4-5 on 64-byte rows): 3 VALU ops per read
             // instead of 6 -- the VALU shares the SIMD's issue port with the MFMAs (C = 64: -4 % same-box)
             const int soff = (second ? tap0 + tl : (tap0 + tl) * d) * ROWB + ks * 64;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int lin = lin0[i] + soff;
-                y[i] = *reinterpret_cast<const f16x8*>(Ys + (lin ^ ((lin >> 3) & (ROWB == 128 ? 0x60 : 0x20))));
+                y[i] = *reinterpret_cast<const f16x8*>(Ys + (lin ^ ((lin >> 3) & (ROWB == 128 ? 0x70 : 0x30))));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) w[j] = *reinterpret_cast<const f16x8*>(Wc + tl * (C * ROWB) + (preW[j] ^ (ks * 64)));

@@ -40,7 +40,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // (chunk XOR term of a row) << 4.  The 16x16x32 operand read of a ds_read_b128 lane group is 8 rows x chunk c and 8 other
 // rows x chunk c ^ 1 (lane l: row l & 15, k group l >> 4), so the term leaves chunk bit 0 alone -- the two halves of a group
 // can then never meet -- and spreads 8 consecutive rows over the 8 slot pairs: conflict-free for ANY first row (a tap is
-// an arbitrary row offset).
+// an arbitrary row offset).  (f = ((r & 7) << 1) ^ ((r >> 2) & 1) would also make the phase-1 epilogue's 16-byte stores of 8
+// consecutive rows conflict-free -- they are 2-way conflicted under this f -- as the 64- / 128-byte-row swizzles of
+// respair.hip and reschain.hip do; measured here: no gain, one more VALU op per address, not adopted.)
 template <int ROWB>
 __device__ __forceinline__ int swz16(int row) {
     if constexpr (ROWB >= 256) return (row & 7) << 5;

@@ -6,5 +6,5 @@ for rep in 1 2 3; do for v in libsi_hip_A.so libsi_hip.so; do
   echo "== $v"
   SI_HIP_LIB=$L/$v python3 bench.py --steps 10 --warmup 3 --cpu-clips 0 --no-fp32-leg > /tmp/b.json 2> /tmp/b.err || { tail -5 /tmp/b.err; exit 1; }
   grep -o '"ms_per_step": [0-9.]*' /tmp/b.json | sed -n 1p
-  grep -i "respair_f16_c" /tmp/b.err | sed -n 1,6p
+  grep -i "respair_f16_c\|reschain" /tmp/b.err | sed -n 1,8p
 done; done

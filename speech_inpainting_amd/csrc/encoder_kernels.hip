@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // accumulators: k-slot i of lane-half h of MFMA step st is score register 8*st + i, i.e. key 16*st + 4*h + (i & 3) +
 // 8*(i >> 2) -- two runs of four consecutive keys, which the V^T operand reads as two 8-byte LDS loads of row d.
 #define ATB_LDK 72    // 64 + 8 halves: 144-byte rows
-#define ATB_LDV 40    // 32 + 8 halves: 80-byte rows
+#define ATB_LDV 36    // 32 + 4 halves: 72-byte rows = 18 banks: the 32 rows of a ds_read_b64 group land on 32 different bank pairs (80-byte rows: rows r and r + 16 collide; PMC conflict share of the kernel 55 %)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __restrict__ qkv, unsigned short* __restrict__ out16, int T,

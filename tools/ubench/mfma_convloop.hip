@@ -6,7 +6,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int READS, int PAIRLOOP, int STAGGER = 0, int PRIO = 0>
+template <int READS, int PAIRLOOP, int STAGGER = 0, int PRIO = 0, int NY = 6, int NW = 2>
 __global__ __launch_bounds__(512, 1) void k(float* out, const _Float16* src, int rounds, int kt, int dd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -15,29 +15,29 @@ __global__ __launch_bounds__(512, 1) void k(float* out, const _Float16* src, int
     __syncthreads();
     const char* As = smem;
     const char* Wc = smem + 56 * 1024;
-    int lin0[6], preW[2];
-    for (int i = 0; i < 6; ++i) lin0[i] = (wave * 96 + 16 * i + r16 + 32) * 64 + (kg << 4);
-    for (int j = 0; j < 2; ++j) preW[j] = (16 * j + r16) * 64 + (kg << 4);
+    int lin0[NY], preW[NW];
+    for (int i = 0; i < NY; ++i) lin0[i] = (wave * 16 * NY + 16 * i + r16 + 32) * 64 + (kg << 4);
+    for (int j = 0; j < NW; ++j) preW[j] = (16 * j + r16) * 64 + (kg << 4);
     const int c = (kt - 1) / 2;
-    f32x4 acc[6][2];
+    f32x4 acc[NY][NW];
     float s = 0.f;
     for (int r = 0; r < rounds; ++r) {
-        for (int i = 0; i < 6; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{(float)r, 0.f, 1.f, 2.f};
-        auto load = [&](f16x8 (&y)[6], f16x8 (&w)[2], int tap) {
+        for (int i = 0; i < NY; ++i) for (int j = 0; j < NW; ++j) acc[i][j] = f32x4{(float)r, 0.f, 1.f, 2.f};
+        auto load = [&](f16x8 (&y)[NY], f16x8 (&w)[NW], int tap) {
             if (!READS && tap > 0) return;
             const int soff = (tap - c) * dd * 64;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { const int lin = lin0[i] + soff; y[i] = *reinterpret_cast<const f16x8*>(As + (lin ^ ((lin >> 3) & 32))); }
+            for (int i = 0; i < NY; ++i) { const int lin = lin0[i] + soff; y[i] = *reinterpret_cast<const f16x8*>(As + (lin ^ ((lin >> 3) & 32))); }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) w[j] = *reinterpret_cast<const f16x8*>(Wc + tap * 2048 + preW[j]);
+            for (int j = 0; j < NW; ++j) w[j] = *reinterpret_cast<const f16x8*>(Wc + tap * (NW * 1024) + preW[j]);
         };
-        auto mma = [&](const f16x8 (&y)[6], const f16x8 (&w)[2]) {
+        auto mma = [&](const f16x8 (&y)[NY], const f16x8 (&w)[NW]) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < NY; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], y[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], y[i], acc[i][j], 0, 0, 0);
         };
-        f16x8 ya[6], wa[2], yb[6], wb[2];
+        f16x8 ya[NY], wa[NW], yb[NY], wb[NW];
         load(ya, wa, 0);
         if constexpr (STAGGER > 0) { if (wave >= 4) __builtin_amdgcn_s_sleep(STAGGER); }
         if constexpr (PAIRLOOP) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512, 1) void k(float* out, const _Float16* src, int
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        for (int i = 0; i < 6; ++i) for (int j = 0; j < 2; ++j) s += acc[i][j][0] + acc[i][j][3];
+        for (int i = 0; i < NY; ++i) for (int j = 0; j < NW; ++j) s += acc[i][j][0] + acc[i][j][3];
         __syncthreads();
     }
     out[blockIdx.x * 512 + tid] = s;
@@ -83,7 +83,7 @@ int main() {
     (void)hipMalloc(&src, h.size() * 2); (void)hipMalloc(&out, (size_t)ncu * 512 * 4);
     (void)hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    auto run = [&](auto kern, const char* name, int kt, int dd) {
+    auto run = [&](auto kern, const char* name, int kt, int dd, int mfma_per_tap = 12) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
         const int R = 20000;
         kern<<<ncu, 512, 100 * 1024>>>(out, src, R / 4, kt, dd);
@@ -93,18 +93,21 @@ int main() {
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
         const double us = ms * 1e3 / R;
-        printf("%-44s k = %2d d = %d: %6.3f us per convolution, %6.1f ns per MFMA and SIMD, %5.0f TFLOP/s\n", name, kt, dd, us, us * 1e3 / (kt * 24), (double)ncu * 8 * kt * 12 * 16384.0 / us * 1e-6);
+        printf("%-44s k = %2d d = %d: %6.3f us per convolution, %6.1f ns per MFMA and SIMD, %5.0f TFLOP/s\n", name, kt, dd, us, us * 1e3 / (kt * 2 * mfma_per_tap), (double)ncu * 8 * kt * mfma_per_tap * 16384.0 / us * 1e-6);
     };
     for (int kt : {3, 7, 11}) {
-        run(k<0, 1>, "no LDS reads after tap 0", kt, 1);
-        run(k<1, 1>, "LDS reads", kt, 1);
-        run(k<1, 1, 0, 1>, "LDS reads, setprio 1 on MFMA blocks", kt, 1);
-        run(k<1, 1, 0, 2>, "LDS reads, setprio 3 / 1 by wave half", kt, 1);
-        run(k<1, 1, 1, 0>, "LDS reads, second half sleeps 64", kt, 1);
-        run(k<1, 1, 2, 0>, "LDS reads, second half sleeps 128", kt, 1);
-        run(k<1, 1, 3, 0>, "LDS reads, second half sleeps 192", kt, 1);
-        run(k<1, 1, 2, 1>, "LDS reads, sleeps 128 + setprio 1", kt, 1);
-        run(k<1, 1, 3, 1>, "LDS reads, sleeps 192 + setprio 1", kt, 1);
+        run(k<0, 1>, "6 x 2 fragments (chain), no LDS reads after tap 0", kt, 1);
+        run(k<1, 1>, "6 x 2 fragments, LDS reads (8 per 12 MFMAs)", kt, 1);
+        run(k<1, 1, 0, 1>, "6 x 2, LDS reads, setprio 1 on MFMA blocks", kt, 1);
+        run(k<1, 1, 2, 0>, "6 x 2, LDS reads, second half sleeps 128", kt, 1);
+        run(k<1, 0>, "6 x 2, LDS reads, one fragment set", kt, 1);
+    }
+    // the 64 x 64 wave tile of the wide kernels / lingemm: 4 + 4 fragment reads per 16 MFMAs (the read addresses move with
+    // the step, so the compiler cannot hoist them as it can in mfma_rate.hip's LDS-fed mode)
+    for (int kt : {8, 32}) {
+        run(k<0, 1, 0, 0, 4, 4>, "4 x 4 fragments, no LDS reads after step 0", kt, 1, 16);
+        run(k<1, 1, 0, 0, 4, 4>, "4 x 4 fragments, LDS reads (8 per 16 MFMAs)", kt, 1, 16);
+        run(k<1, 1, 0, 1, 4, 4>, "4 x 4, LDS reads, setprio 1 on MFMA blocks", kt, 1, 16);
     }
     return 0;
 }

@@ -20,9 +20,9 @@
 // tile loads, and no fp32 output image at all -- the residual add happens in the accumulator layout against X in LDS.
 //
 // What bounds it (timeline build + tools/ubench/mfma_convloop.hip): with N = 32 a 1 KB activation fragment feeds only two
-// MFMAs, so a tap costs every wave 8 ds_read_b128 per 12 MFMAs; the CU's LDS delivers ~210 B/ns to this access pattern
-// (half of the 256 B/clk table value at the clock the chip holds), which is 13 ns per MFMA and SIMD against 8.7 for the
-// matrix pipe alone -- the tap loop runs at the LDS rate whatever the schedule (fragment double buffer or not, wave
+// MFMAs, so a tap costs every wave 8 ds_read_b128 per 12 MFMAs; next to the MFMA stream these reads reach ~210 B/ns per
+// CU (alone they stream at 380-490: tools/ubench/lds_read_rate.hip), which is 13 ns per MFMA and SIMD against 8.7-9.7
+// for the matrix pipe alone -- the tap loop runs at that rate whatever the schedule (fragment double buffer or not, wave
 // priorities, staggered waves: all within 2 %).  The epilogues were bound by 4-way bank conflicts of 8-byte stores in the
 // accumulator layout (16 lanes = one column of 16 rows on 64-byte rows); lanes l and l + 16 now trade halves
 // (v_permlane16_swap) and store whole 16-byte chunks.

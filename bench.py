@@ -187,6 +187,23 @@ def roofline_of(prof, steps, table=None, table_steps=0):
     return roof, fams, tot
 
 
+def spawn_ranks(n: int) -> int:
+    """Launch `n` ranks of this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) as a
+    child process; its stdout (rank 0's one JSON line) and stderr pass through.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this pool's host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] --gpus {n} without WORLD_SIZE: launching {' '.join(cmd[1:8])} ...")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +218,12 @@ def main():
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the secondary exact-fp32-vocoder leg")
     ap.add_argument("--graph-leg", action="store_true", help="also replay the step as one hipGraph (informational)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes and relay rank 0's JSON
+        # line.  Done before anything here touches the GPU (torch.cuda.device_count() does not initialise it), and as a
+        # child process, never an exec of this one.
+        raise SystemExit(spawn_ranks(a.gpus))
 
     from speech_inpainting_amd import parallel, synth
     from speech_inpainting_amd.arch import HubertArch, VocoderArch, mel_frames
@@ -363,6 +386,12 @@ def main():
 
     if main_run["prof"]:
         res["roofline"], res["kernel_families"] = table(main_run, f"{a.encoder_dtype}/{a.vocoder_dtype}")
+    if "bf16x3" in legs:
+        # the number of record at the REFERENCE's vocoder precision (fp32-equivalent operands), next to `value`
+        res["reference_precision_value"] = round(headline(legs["bf16x3"]), 2)
+        res["reference_precision_note"] = ("same step with the vocoder on bf16x3 (every fp32 operand split hi + lo, fp32 accumulate, fp32 "
+                                           "activations: 1.5e-6 waveform RMS vs the fp32 reference); `value` is the fp16-MFMA vocoder "
+                                           "(1.35e-4 RMS, inside the 1e-3 gate)")
     for voc, r in legs.items():
         leg = {"value": round(headline(r), 2), "ms_per_step": round(1e3 * r["elapsed"] / r["steps"], 3),
                "steps": r["steps"], "dtype": f"encoder {a.encoder_dtype}, vocoder {dtype_txt[voc]}"}

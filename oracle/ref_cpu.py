@@ -380,8 +380,8 @@ def f0_encoder_forward(state: dict, f0: torch.Tensor, down_t: int = 4, stride_t:
     :200-262 with one level of `EncoderConvBlock` (:11-116): down_t x [Conv1d(k = 2 s, stride s, pad s / 2) (:54-68, odd s:
     2 s + 1 / s // 2 + 1) -> Resnet1D (resnet.py:57-97): depth x `x + Conv1d_k1(ReLU(Conv1d_k3(ReLU(x), dilation =
     growth ** j, padding = dilation)))` (:29-54, res_scale 1)] -> Conv1d(width, out, 3, 1, 1) (:80-82).
-    f0 (B, 1, T) -> (B, out_width, T // stride ** down_t).  PARITY UNPINNED: `src.modules` needs no exotic imports, but
-    I_da is outside what may be imported here and the reference holds no fixture; restated from the source text."""
+    f0 (B, 1, T) -> (B, out_width, T // stride ** down_t).  Pinned by tests/golden/f0_vqvae.npz: outputs of the reference's
+    own `Encoder` loaded by file path (tools/make_goldens.py::f0_vqvae_cases), reproduced bit for bit."""
     pre = "encoder.level_blocks.0.model."
     k, pad = (2 * stride_t, stride_t // 2) if stride_t % 2 == 0 else (2 * stride_t + 1, stride_t // 2 + 1)
     x = f0.float()
@@ -398,7 +398,8 @@ def f0_encoder_forward(state: dict, f0: torch.Tensor, down_t: int = 4, stride_t:
 
 def f0_vq_codes(h: torch.Tensor, k: torch.Tensor) -> torch.Tensor:
     """f-2.  `BottleneckBlock.encode` (I_da/src/modules/vq.py:133-144): h (N, C, T) -> permute / flatten (:92-95) ->
-    arg-min over bins of |x|^2 - 2 x.k^T + |k|^2 (:117-127) -> (N, T) int64.  PARITY UNPINNED (as above)."""
+    arg-min over bins of |x|^2 - 2 x.k^T + |k|^2 (:117-127) -> (N, T) int64.  Pinned by tests/golden/f0_vqvae.npz (the
+    reference's `Bottleneck.forward` in eval mode, which is what `CodeGenerator.forward` calls at model.py:164)."""
     n, c, t = h.shape
     x = h.permute(0, 2, 1).reshape(-1, c).float()
     kw = k.float().t()

@@ -89,6 +89,17 @@ class HubertArch:
             feat_proj_layer_norm=bool(cfg.get("feat_proj_layer_norm", True)),
             codebook_dim=codebook_dim)
 
+    def to_hf(self) -> dict:
+        """The HuggingFace `config.json` dict of this architecture (the schema of I_ea/dataset/config.json:62-124)."""
+        return dict(model_type="hubert", hidden_size=self.hidden_size, num_hidden_layers=self.num_hidden_layers,
+                    num_attention_heads=self.num_attention_heads, intermediate_size=self.intermediate_size,
+                    conv_dim=list(self.conv_dim), conv_kernel=list(self.conv_kernel), conv_stride=list(self.conv_stride),
+                    conv_bias=self.conv_bias, feat_extract_norm=self.feat_extract_norm, feat_extract_activation="gelu",
+                    hidden_act="gelu", do_stable_layer_norm=self.do_stable_layer_norm,
+                    num_conv_pos_embeddings=self.num_conv_pos_embeddings,
+                    num_conv_pos_embedding_groups=self.num_conv_pos_embedding_groups, layer_norm_eps=self.layer_norm_eps,
+                    feat_proj_layer_norm=self.feat_proj_layer_norm, num_feat_extract_layers=len(self.conv_dim))
+
     @classmethod
     def from_json(cls, path: str, codebook_dim: int = 80) -> "HubertArch":
         with open(path) as f:

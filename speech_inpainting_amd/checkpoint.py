@@ -76,6 +76,18 @@ def load_hubert_checkpoint(path: str, model_type: Optional[str] = None) -> Tuple
     return normalize_hubert_keys(sd), arch
 
 
+def fresh_final_layers(arch: HubertArch, seed: int = 1234) -> Dict[str, torch.Tensor]:
+    """`final_layers = Sequential(LayerNorm(H), Linear(H, codebook_dim))` as the reference's constructor leaves it when it
+    starts from a pretrained encoder (`load_pretrained=True`, I_ea/model.py:26-40,75-78): PyTorch's default initialisation.
+    A HuggingFace directory holds the encoder only; the trained head lives in the CustomModel .pt (I_ea/predict.py:149)."""
+    g = torch.Generator().manual_seed(seed)
+    H, D = arch.hidden_size, arch.codebook_dim
+    bound = H ** -0.5                       # kaiming_uniform(a = sqrt(5)) on (D, H) and the bias bound 1 / sqrt(fan_in)
+    return {"final_layers.0.weight": torch.ones(H), "final_layers.0.bias": torch.zeros(H),
+            "final_layers.1.weight": (torch.rand(D, H, generator=g) * 2 - 1) * bound,
+            "final_layers.1.bias": (torch.rand(D, generator=g) * 2 - 1) * bound}
+
+
 def load_generator_checkpoint(path: str) -> Tuple[Dict[str, torch.Tensor], VocoderArch]:
     """`hifi_gan.checkpoint_file` of predict.yaml; `config.json` must sit beside it (I_ea/predict.py:110-115)."""
     cfg = os.path.join(os.path.split(path)[0], "config.json")

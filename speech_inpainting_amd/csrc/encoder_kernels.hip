@@ -388,8 +388,8 @@ int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const flo
     if (C % 4 != 0 || C > 2048) return si_fail(ctx, SI_EINVAL, "layernorm width %d must be a multiple of 4 and <= 2048", C);
     if (rows <= 0) return SI_OK;
     // 16 waves per CU (four 4-wave workgroups), each walking its share of the rows (same-box A/B over 8 / 16 / 32 waves
-    // per CU and one row per wave: 0.40 / 0.35 / 0.36 / 0.37 ms per step); SI_LN_WAVES overrides the per-CU count
-    static const int per_cu = getenv("SI_LN_WAVES") ? std::max(1, atoi(getenv("SI_LN_WAVES")) / 4) : 4;
+    // per CU and one row per wave: 0.40 / 0.35 / 0.36 / 0.37 ms per step)
+    constexpr int per_cu = 4;
     dim3 grid((unsigned)std::min<long>((rows + 3) / 4, (long)si_num_cus(ctx) * per_cu));
     si_prof_begin(ctx, "layernorm", 8.0 * rows * C, 8.0 * rows * C, st);
     if (gelu) hipLaunchKernelGGL(layernorm_kernel<true>, grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);

@@ -260,10 +260,8 @@ int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     if (!p.out && !p.out16) return si_fail(ctx, SI_EINVAL, "lingemm: no output");
     // Tile height: the workgroup slots are 2 per CU; a launch takes ceil(tiles / slots) rounds of a tile's time, which
     // grows with BM (plus a fixed part: prologue, epilogue).  Pick the BM with the smallest rounds x (BM + fixed).
-    static const int force = getenv("SI_LG_BM") ? atoi(getenv("SI_LG_BM")) : 0;
     int bm = 128;
-    if (force == 64 || force == 96 || force == 128) bm = force;
-    else {
+    {
         const long slots = 2L * si_num_cus(ctx);
         double best = 1e30;
         for (int cand : {128, 96, 64}) {

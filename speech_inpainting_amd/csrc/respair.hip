@@ -326,7 +326,7 @@ static int respair_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t st) {
     char name[48];
     snprintf(name, sizeof(name), p.accumulate ? "respair_f16_c%d_acc" : "respair_f16_c%d", C);   // one family per instantiation
     const double elems = (double)p.B * p.L * C;
-    si_prof_begin(ctx, name, 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 2.0 * 2.0 * p.k * C * C, st);
+    si_prof_begin(ctx, name, 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 2.0 * 2.0 * p.k * C * C, st);   // y read once (it is also the residual), out written [, previous out read]
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WARPS_M), lds, st, p);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());

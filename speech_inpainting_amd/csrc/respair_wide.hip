@@ -387,14 +387,13 @@ static int respair_wide_launch(si_ctx* ctx, const ResPairParams& p0, hipStream_t
     const size_t lds = (size_t)(R1 + RPW_HALO) * C * 2 + 2 * (size_t)C * BKW * 2 + 2 * (size_t)C * 4;
     auto kern = p.accumulate ? respair_wide_kernel<C, R1, WARPS_M, WARPS_N, BKW, true> : respair_wide_kernel<C, R1, WARPS_M, WARPS_N, BKW, false>;
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), lds)) return rc;
-    // one persistent workgroup per CU (144-157 KB of LDS each); SI_RP_PERSIST=0 launches one workgroup per tile instead
-    static const int persist = getenv("SI_RP_PERSIST") ? atoi(getenv("SI_RP_PERSIST")) : 1;
+    // one persistent workgroup per CU (144-157 KB of LDS each) walking tiles blockIdx.x + i * gridDim.x
     const int total = ((p.L + BMo - 1) / BMo) * p.B;
-    const int grid = persist ? std::min(total, si_num_cus(ctx) * (WARPS_M * WARPS_N == 4 ? 2 : 1)) : total;
+    const int grid = std::min(total, si_num_cus(ctx) * (WARPS_M * WARPS_N == 4 ? 2 : 1));
     char name[48];
     snprintf(name, sizeof(name), p.accumulate ? "respair_f16_c%d_acc" : "respair_f16_c%d", C);   // one family per instantiation
     const double elems = (double)p.B * p.L * C;
-    si_prof_begin(ctx, name, 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 2.0 * 2.0 * p.k * C * C, st);
+    si_prof_begin(ctx, name, 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 2.0 * 2.0 * p.k * C * C, st);   // y read once (it is also the residual), out written [, previous out read]
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WARPS_M * WARPS_N), lds, st, p);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());

@@ -45,7 +45,7 @@ def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
     RCCL ("nccl") broadcasts device memory directly over xGMI.  The gloo backend exists only to rehearse N > 1 ranks
     without N GPUs (CPU tests; several ranks sharing one card): it has no device transport here, so a device blob is
     staged through host memory around the same collective."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         return blob
     if blob.is_cuda and dist.get_backend() == "gloo":
         host = blob.cpu()
@@ -60,7 +60,7 @@ def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
 def gather_metrics(values: Sequence[float], device="cpu") -> torch.Tensor:
     """All-gather a per-rank vector -> (world, len) float64 tensor on every rank."""
     v = torch.tensor(list(values), dtype=torch.float64, device=device)
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         return v[None]
     out = [torch.empty_like(v) for _ in range(dist.get_world_size())]
     dist.all_gather(out, v)
@@ -68,7 +68,7 @@ def gather_metrics(values: Sequence[float], device="cpu") -> torch.Tensor:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
 
 

@@ -112,6 +112,78 @@ def test_checkpoint_files_roundtrip(tmp_path):
     assert set(sd3) == set(hsd) and arch.hidden_size == 768
 
 
+def _write_hf_dir(path, arch, sd, fmt="safetensors"):
+    import json
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(arch.to_hf(), f)
+    if fmt == "safetensors":
+        from safetensors.torch import save_file
+        save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    else:
+        torch.save(dict(sd), os.path.join(path, "pytorch_model.bin"))
+
+
+def test_local_huggingface_directory_loader(tmp_path):
+    """The "HuggingFace checkpoint loader" of the north star: a LOCAL directory with config.json + model.safetensors (or
+    pytorch_model.bin) stands in for `HubertModel.from_pretrained(name)` / `HubertConfig.from_pretrained(name)`
+    (I_ea/model.py:26-40), with bare `HubertModel` keys and with the `hubert.`-prefixed keys of a `HubertForCTC` file
+    (facebook/hubert-large-ls960-ft is one)."""
+    assert HubertArch.from_hf_config(HubertArch.base().to_hf()) == HubertArch.base()
+    assert HubertArch.from_hf_config(HubertArch.large().to_hf()) == HubertArch.large()
+    ha = HubertArch.tiny()
+    hsd = synth.synth_hubert_state(ha)
+    bare = {k[len("base_model."):]: v for k, v in hsd.items() if k.startswith("base_model.")}
+    bare["masked_spec_embed"] = torch.zeros(ha.hidden_size)                       # present in real files, unused in eval
+    want = {k: v for k, v in hsd.items() if k.startswith("base_model.")}
+    _write_hf_dir(str(tmp_path / "bare"), ha, bare)
+    sd, arch = checkpoint.load_hubert_checkpoint(str(tmp_path / "bare"))
+    assert arch == ha and set(sd) == set(want) and all(torch.equal(sd[k], want[k]) for k in want)
+    ctc = {"hubert." + k: v for k, v in bare.items()}
+    ctc["lm_head.weight"], ctc["lm_head.bias"] = torch.zeros(32, ha.hidden_size), torch.zeros(32)
+    _write_hf_dir(str(tmp_path / "ctc"), ha, ctc, fmt="bin")
+    sd2, arch2 = checkpoint.load_hubert_checkpoint(str(tmp_path / "ctc"))
+    assert arch2 == ha and set(sd2) == set(want) and all(torch.equal(sd2[k], want[k]) for k in want)
+    # the in-tree dump of the base config (I_ea/dataset/config.json:62-124) gives the base architecture
+    with pytest.raises(FileNotFoundError, match="neither"):
+        os.makedirs(tmp_path / "empty")
+        checkpoint.load_hubert_checkpoint(str(tmp_path / "empty"))
+    # a directory holds the encoder only; the head comes from the CustomModel .pt or is freshly initialised as the
+    # reference's constructor initialises it (I_ea/model.py:75-78)
+    head = checkpoint.fresh_final_layers(ha, seed=1234)
+    assert head["final_layers.0.weight"].shape == (ha.hidden_size,) and head["final_layers.1.weight"].shape == (80, ha.hidden_size)
+    assert float(head["final_layers.0.weight"].min()) == 1.0 and float(head["final_layers.1.weight"].abs().max()) <= ha.hidden_size ** -0.5 + 1e-6
+
+
+def test_bench_spawns_its_own_ranks_when_world_size_is_unset(monkeypatch):
+    """`python bench.py --gpus N` without a launcher: N ranks under torch.distributed.run as a CHILD process (never an exec),
+    rendezvous on 127.0.0.1, before anything touches the GPU."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    class _Done:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return _Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("GPU touched before the spawn")))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    c = seen["cmd"]
+    assert c[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in c and "127.0.0.1" in c
+    assert c[-4:] == ["--gpus", "4", "--steps", "3"] and c[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
 def test_shard_range_partitions_exactly():
     for n in (0, 1, 7, 32, 256, 257):
         for w in (1, 2, 3, 8):

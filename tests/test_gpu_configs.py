@@ -223,7 +223,7 @@ def test_f0_vqvae_front_matches_oracle(B, T):
     """Row f-2, the F0 side of `CodeGenerator.forward` (I_da/src/model.py:160-166): the fixed VQ-VAE's conv encoder
     (si_f0_encoder_forward: 4 x [stride-2 conv + 4 dilated res blocks] + conv, hubert_lut.json:42-52), its bottleneck's
     arg-min (si_kmeans_assign) and the embedding look-up -- against the oracle's restatement of jukebox.py / resnet.py /
-    vq.py (parity unpinned: I_da is not importable).  fp32 MACs in a different order: 1e-5 relative; codes equal wherever
+    vq.py (itself pinned by tests/golden/f0_vqvae.npz).  fp32 MACs in a different order: 1e-5 relative; codes equal wherever
     the two nearest bins are not within rounding of each other."""
     from oracle import ref_cpu as R
     from speech_inpainting_amd import native, synth
@@ -267,3 +267,37 @@ def test_f0_vqvae_front_matches_oracle(B, T):
         eng.ctx.f0_encoder(desc, q.weights[:-1].contiguous(), f0.cuda())
     with pytest.raises(ValueError):
         eng.ctx.f0_encoder(desc, q.weights, f0[:, :, :8].contiguous().cuda())
+
+
+@pytest.mark.gpu
+def test_f0_vqvae_front_matches_reference_goldens():
+    """Row f-2 against the REFERENCE: `si_f0_encoder_forward` + `si_kmeans_assign` on the inputs of tests/golden/f0_vqvae.npz
+    against the outputs of the reference's own `Encoder` / `Bottleneck` modules (I_da/src/modules/jukebox.py, vq.py; fixture
+    written by tools/make_goldens.py::f0_vqvae_cases): encoder output <= 1e-5 relative, codes identical except where the
+    reference's own two best distances are within fp32 rounding of each other."""
+    import os
+    from speech_inpainting_amd import native, synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import F0Quantizer, InpaintingEngine
+    from tests.common import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "f0_vqvae.npz"))
+    harch, varch = HubertArch.tiny(), VocoderArch.tiny()
+    eng = InpaintingEngine(harch, varch, 20, "cuda:0", "fp32", "fp32")
+    desc = native.F0EncDesc()
+    sd = synth.synth_f0_vqvae_state(desc, 20, seed=11)
+    q = F0Quantizer(eng, sd, desc)
+    k = sd["vq.level_blocks.0.k"]
+    for T in (64, 800, 1000):
+        f0 = torch.from_numpy(z[f"f0_{T}"])
+        ref = torch.from_numpy(z[f"h_{T}"])                                       # (B, 128, T / 16)
+        h = q.features(f0.cuda()).cpu()                                           # (B, T / 16, 128)
+        rel = rms(h, ref.transpose(1, 2)) / rms(ref)
+        codes = q(f0.cuda()).cpu()
+        want = torch.from_numpy(z[f"codes_{T}"])
+        agree = float((codes == want).float().mean())
+        print(f"T={T}: encoder output vs reference {rel:.2e} relative, codes agree {agree:.3f}")
+        assert rel <= 1e-5
+        x = ref.permute(0, 2, 1).reshape(-1, 128)
+        d = ((x[:, None, :] - k[None]) ** 2).sum(-1)
+        dz, dr = d.gather(1, codes.reshape(-1, 1)), d.gather(1, want.reshape(-1, 1))
+        assert bool(((dz - dr).abs() <= 1e-4 * dr.abs() + 1e-6).all()) and agree >= 0.98

@@ -40,8 +40,6 @@ COMBOS = [
     {"SI_VOC_RES16": "0", "SI_VOC_OPREADY": "0", "SI_ENC_OPREADY": "0", "SI_ATT_BF16": "0"},   # every non-default arithmetic path at once
     {"SI_ENC_LINGEMM": "0"},                                 # encoder GEMMs on the generic tap-GEMM
     {"SI_VOC_CHAIN": "0"},                                   # C = 32 stage as one launch per conv pair instead of per resblock
-    {"SI_LG_BM": "64"},                                      # every encoder GEMM on 64-row tiles (the rule mixes 64 / 96 / 128)
-    {"SI_LG_BM": "96"},
 ]
 
 

@@ -39,6 +39,30 @@ def test_ranks_share_one_gpu_and_match_the_single_batch_run(nproc, enc, voc):
     assert r["ok"] and r["world"] == nproc and sum(r["clips"]) == 7
 
 
+def test_rccl_accepts_the_library_owned_weight_blob():
+    """backend="nccl", world size 1: ProcessGroupNCCL init with device_id, dist.broadcast on the __cuda_array_interface__ view of the
+    library's hipMalloc blob, device-side all_gather and barrier -- issued by parallel.py's own functions (tests/nccl_worker.py)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_worker.py"), str(_free_port())], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("NCCL_OK ")][-1][len("NCCL_OK "):])
+    assert r["ok"] and r["backend"] == "nccl" and r["blob_bytes"] > 0
+
+
+def test_bench_gpus_flag_without_a_launcher_spawns_the_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver starts the N = 1 line) must launch its own ranks as
+    child processes and relay rank 0's JSON line (gloo here: two ranks share this box's one GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SI_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--no-fp32-leg", "--cpu-clips", "0"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 8 and r["value"] > 0
+
+
 def test_bench_two_rank_rehearsal_prints_the_contract_line():
     """bench.py --gpus 2 launched exactly as the driver launches it, but with SI_DIST_BACKEND=gloo so two ranks can share
     this box's GPU (small batch: the point is the rendezvous, the broadcast into si_alloc_weights memory, the barrier /

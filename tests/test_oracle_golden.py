@@ -112,8 +112,31 @@ def test_padded_batches_match_reference_goldens():
         assert float((nomask[1] - ref[1]).pow(2).mean().sqrt()) > 1e-3
 
 
+def test_f0_vqvae_restatement_matches_the_reference_modules():
+    """Row f-2: `oracle.f0_encoder_forward` / `f0_vq_codes` against the outputs of the reference's OWN `Encoder`
+    (I_da/src/modules/jukebox.py:200-262) and `Bottleneck` (vq.py:183-232) for seeded weights in the hubert_lut.json:36-52
+    shape, T = 64 / 800 / 1000 F0 frames (tests/golden/f0_vqvae.npz, written by tools/make_goldens.py::f0_vqvae_cases)."""
+    import numpy as np
+    import torch
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import native, synth
+    from tests.common import GOLDEN
+    import os
+    z = np.load(os.path.join(GOLDEN, "f0_vqvae.npz"))
+    sd = synth.synth_f0_vqvae_state(native.F0EncDesc(), 20, seed=11)
+    assert np.allclose([float(sd["encoder.level_blocks.0.model.0.0.weight"][0, 0, 0]), float(sd["vq.level_blocks.0.k"][0, 0])], z["probe"], atol=1e-7)
+    for T in (64, 800, 1000):
+        h = R.f0_encoder_forward(sd, torch.from_numpy(z[f"f0_{T}"]))
+        ref = torch.from_numpy(z[f"h_{T}"])
+        assert h.shape == ref.shape == (2, 128, T // 16)
+        assert float((h - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+        codes = R.f0_vq_codes(h, sd["vq.level_blocks.0.k"])
+        assert np.array_equal(codes.numpy(), z[f"codes_{T}"])                    # bit-exact indices
+        assert len(set(z[f"codes_{T}"].reshape(-1).tolist())) >= 4               # the fixture exercises several bins
+
+
 def test_f0_encoder_restatement_shapes_and_known_answer():
-    """The oracle's F0 VQ-VAE encoder (row f-2, parity unpinned) against a direct evaluation of its definition on a
+    """The oracle's F0 VQ-VAE encoder (row f-2) against a direct evaluation of its definition on a
     hand-checkable case: all-zero convolution weights leave only the biases, so every res block adds its k1 bias and
     the last conv returns its bias; and T frames come out as T // 16."""
     import torch

@@ -265,6 +265,85 @@ def padded_cases(out_dir):
     np.savez_compressed(os.path.join(out_dir, "padded.npz"), **rec)
 
 
+def _load_ida_modules():
+    """`I_da/src/modules/{dist,resnet,jukebox,vq}.py` loaded BY FILE PATH under empty `src` / `src.modules` namespace modules
+    (the package's own `__init__` imports files that are not in the tree, I_da/src/modules/__init__.py:1-5); nothing is
+    stubbed: the four files import only torch / numpy and each other."""
+    import importlib.util
+    base = os.path.join(REF, "I_da", "src", "modules")
+    for pkg in ("src", "src.modules"):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = []
+            sys.modules[pkg] = m
+    mods = {}
+    for name in ("dist", "resnet", "jukebox", "vq"):
+        full = f"src.modules.{name}"
+        spec = importlib.util.spec_from_file_location(full, os.path.join(base, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[full] = mod
+        spec.loader.exec_module(mod)
+        mods[name] = mod
+    return mods
+
+
+def synth_f0_track(B, T, seed):
+    """A normalised-F0-like track (B, 1, T): voiced stretches of a smooth contour, zeros where unvoiced (what
+    `normalize_nonzero` leaves, I_da/scripts/inpainting.py:216-217)."""
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(T, dtype=torch.float32)
+    out = torch.zeros(B, 1, T)
+    for b in range(B):
+        ph = torch.rand(3, generator=g) * 6.28318
+        c = 0.9 * torch.sin(t / 37.0 + ph[0]) + 0.5 * torch.sin(t / 11.0 + ph[1]) + 0.2 * torch.randn(T, generator=g)
+        voiced = (torch.sin(t / 53.0 + ph[2]) > -0.3).float()
+        out[b, 0] = c * voiced
+    return out
+
+
+def f0_vqvae_cases(out_dir):
+    """The fixed F0 VQ-VAE front of `CodeGenerator.forward` (I_da/src/model.py:160-166) from the reference's OWN modules:
+    `Encoder(**f0_encoder_params)` (jukebox.py:200-262) and `Bottleneck(**f0_vq_params)` in eval mode (vq.py:183-232 ->
+    BottleneckBlock.forward :156-180 -> quantise :117-127), hubert_lut.json:36-52 shapes, seeded weights.  The bottleneck's
+    constructor puts its codebook on `.cuda()` (vq.py:22) and there is no GPU here, so the two bottleneck objects are
+    assembled without `__init__` (attributes as :11-17,185-190 set them, the buffer on the CPU) and the reference's own
+    `forward` / `encode` methods are then called."""
+    import torch.nn as nn
+    from speech_inpainting_amd.native import F0EncDesc
+    mods = _load_ida_modules()
+    Encoder, Bottleneck, BottleneckBlock = mods["jukebox"].Encoder, mods["vq"].Bottleneck, mods["vq"].BottleneckBlock
+    desc = F0EncDesc()
+    l_bins = 20
+    sd = synth.synth_f0_vqvae_state(desc, l_bins, seed=11)
+    enc = Encoder(input_emb_width=1, output_emb_width=128, levels=1, downs_t=[4], strides_t=[2], width=32, depth=4, m_conv=1.0,
+                  dilation_growth_rate=3)                                   # hubert_lut.json:42-52
+    missing, unexpected = enc.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}, strict=True)
+    enc.eval()
+    blk = BottleneckBlock.__new__(BottleneckBlock)
+    nn.Module.__init__(blk)
+    blk.k_bins, blk.emb_width, blk.mu, blk.threshold = l_bins, 128, 0.99, 1.0     # vq.py:11-17
+    blk.init, blk.k_sum, blk.k_elem = False, None, None                            # reset_k, :19-22, minus .cuda()
+    blk.register_buffer("k", sd["vq.level_blocks.0.k"].clone())
+    vq = Bottleneck.__new__(Bottleneck)
+    nn.Module.__init__(vq)
+    vq.levels = 1
+    vq.level_blocks = nn.ModuleList([blk])
+    vq.eval()
+    rec = {"probe": np.asarray([float(sd["encoder.level_blocks.0.model.0.0.weight"][0, 0, 0]), float(sd["vq.level_blocks.0.k"][0, 0])], np.float64)}
+    for T in (64, 800, 1000):
+        f0 = synth_f0_track(2, T, 300 + T)
+        with torch.no_grad():
+            h_p = [x.detach() for x in enc(f0)]                                   # model.py:162
+            z_p = [x.detach() for x in vq(h_p)[0]][0].detach()                     # model.py:164
+            z_enc = vq.encode(h_p)[0]                                              # vq.py:191-193 (same indices)
+        assert torch.equal(z_p, z_enc)
+        rec[f"f0_{T}"] = f0.numpy()
+        rec[f"h_{T}"] = h_p[0].numpy()
+        rec[f"codes_{T}"] = z_p.numpy().astype(np.int64)
+        print(f"f0_vqvae T={T}: h {tuple(h_p[0].shape)} rms {rms(h_p[0]):.4f}  codes[0][:12] {z_p[0][:12].tolist()}  distinct {len(set(z_p.reshape(-1).tolist()))}")
+    np.savez_compressed(os.path.join(out_dir, "f0_vqvae.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
@@ -291,6 +370,7 @@ def main():
         "extend_mel": lambda: extend_cases(a.out),
         "loss_metrics": lambda: loss_cases(a.out, tmp),
         "padded": lambda: padded_cases(a.out),
+        "f0_vqvae": lambda: f0_vqvae_cases(a.out),
     }
     for k, fn in cases.items():
         if a.only and k not in a.only.split(","):

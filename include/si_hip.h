@@ -14,6 +14,9 @@
  *   si_sisdr             <- Metrics.sisdr (row f-4)                                 I_ea/metrics.py:127-142
  *   si_unit_frontend     <- CodeGenerator.forward's embedding / _upsample / concat front (row f-2)   I_da/src/model.py:79-119,148-189
  *   si_f0_encoder_forward <- FoVQVAE.encoder(fo) inside CodeGenerator.forward (row f-2)   I_da/src/model.py:160-163 ; I_da/src/modules/jukebox.py:11-116,200-262
+ *   si_hubert_extract_features <- HubertFeatureReader.get_feats (row f-2)   I_da/src/hubert_feature_reader.py:44-67 (called at
+ *                           I_da/scripts/inpainting.py:195-198) + the corruption `(y + 1e-6) * mask` in front of it (:186-192)
+ *   si_code_splice       <- the unit splice (row f-2)                        I_da/scripts/inpainting.py:209-214
  *   si_kmeans_assign     <- kmeans_model.predict(feats) (row f-2)   I_da/scripts/inpainting.py:204-205 ;
  *                           ApplyKmeans.__call__                    I_ea/dataset/km_label.py:20-24
  *   si_resample_poly     <- librosa.load(..., sr=22050 / 16000) resampling (row f-3)   I_ea/predict.py:79-80
@@ -144,6 +147,38 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
 int si_hubert_forward_padded(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len,
                              const int32_t* valid_len, int normalize, int B, int N, float* out_feats, void* workspace,
                              size_t workspace_bytes, si_stream_t stream);
+
+/* I_da's encoder call: `HubertFeatureReader.get_feats` (I_da/src/hubert_feature_reader.py:44-67) =
+ * optional `F.layer_norm(x, x.shape)` over the whole clip (:53-54, when the checkpoint's task.cfg.normalize is set) followed by
+ * fairseq's `model.extract_features(source, padding_mask=None, mask=False, output_layer=L)` (:60-65): the feature extractor,
+ * LayerNorm + projection, positional conv, then transformer layers 0..L-1 ONLY; the output is layer L-1's output (B, T, H) --
+ * in the pre-LN ("layer_norm_first") flavour the residual stream WITHOUT the encoder's final LayerNorm, which fairseq
+ * applies only when no layer is requested.  No head, no codebook.
+ * fairseq is not in the build image and the reference pins no version of it; the arithmetic is the HuBERT architecture
+ * this library already implements for I_ea (the transformers port of the same checkpoints), so the entry is pinned
+ * against `HubertModel(..., output_hidden_states=True).hidden_states[L]` (tests/golden/hidden_layers.npz).
+ * mask_start / mask_len (device int32 (B), samples, or NULL) and pre_mask_add (device fp64 (B) or NULL) restate the
+ * script's corruption `y_inpainting = (y + 1e-6) * mask` on the float64 clip (I_da/scripts/inpainting.py:186-192): the
+ * addend is applied in fp64 to every sample of clip b and rounded to fp32 once, then the span is zeroed -- fused into
+ * the first conv's loaders like I_ea's mask.  Clips of the clean stream pass mask_len = 0 and pre_mask_add = 0. */
+typedef struct si_extract_desc {
+    int32_t struct_size;        /* = sizeof(si_extract_desc) */
+    int32_t output_layer;       /* L in 1..num_layers */
+    int32_t normalize;          /* 0: wav is used as is; 1: HF processor (x - mean) / sqrt(var + 1e-7) (I_ea);
+                                   2: F.layer_norm(x, x.shape): (x - mean) / sqrt(var + 1e-5) (I_da, task.cfg.normalize) */
+    int32_t reserved;
+} si_extract_desc;
+int si_hubert_extract_features(si_ctx* ctx, const si_extract_desc* x, const float* wav, const int32_t* mask_start,
+                               const int32_t* mask_len, const double* pre_mask_add, int B, int N, float* out_hidden,
+                               void* workspace, size_t workspace_bytes, si_stream_t stream);
+
+/* I_da's code splice (I_da/scripts/inpainting.py:209-214): the units predicted from the corrupted clip survive only
+ * inside the mask -- `code_inpainting[: fs // hop] = code[: fs // hop]; code_inpainting[(fs + ms) // hop :] = code[...]`:
+ * out[b][t] = (t < first[b] || t >= last[b]) ? code_clean[b][t] : code_masked[b][t], first = frame_start // code_hop_size,
+ * last = (frame_start + mask_size) // code_hop_size.  code_* / out device int64 (B, T) (out may alias code_masked);
+ * first / last device int32 (B).  Needs no weights. */
+int si_code_splice(si_ctx* ctx, const int64_t* code_clean, const int64_t* code_masked, const int32_t* first, const int32_t* last,
+                   int B, int T, int64_t* out, si_stream_t stream);
 
 /* Codeword decision + splice: for b, j < Lm:  label = argmax_k cos(feats[b, pos_b + j], C_k - mean(C));
  * mel[b, :, pos_b + j] = C_label.   feats (B, T, D); frame_pos device int32 (B); mel (B, D, Tm) in/out;

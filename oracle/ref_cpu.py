@@ -227,7 +227,7 @@ def hubert_pos_conv(sd, arch, prefix: str, h: torch.Tensor) -> torch.Tensor:
 
 
 def hubert_encode(sd, arch, x_norm: torch.Tensor, prefix: str = "base_model.", taps: Optional[dict] = None,
-                  attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  attention_mask: Optional[torch.Tensor] = None, output_layer: Optional[int] = None) -> torch.Tensor:
     """A1..A8.  HubertModel.forward in eval mode (modeling_hubert.py:878-947; encoder :407-476 post-LN, :550-623 pre-LN
     'stable').  attention_mask (B, N) 0/1 over SAMPLES (right-padded batches), or None = all ones: the feature extractor
     and the projection see the whole padded input; the frame-level mask (:679-689) then zeroes the padded frames of the
@@ -268,9 +268,99 @@ def hubert_encode(sd, arch, x_norm: torch.Tensor, prefix: str = "base_model.", t
             h = F.layer_norm(h, (H,), sd[L + "final_layer_norm.weight"].float(), sd[L + "final_layer_norm.bias"].float(), eps)
         if taps is not None and l == 0:
             taps["layer0"] = h
+        if output_layer is not None and l + 1 == output_layer:
+            return h                       # fairseq extract_features(output_layer=L): layer L-1's output, no final LayerNorm
     if arch.do_stable_layer_norm:
         h = F.layer_norm(h, (H,), sd[e + "layer_norm.weight"].float(), sd[e + "layer_norm.bias"].float(), eps)
     return h
+
+
+# ----------------------------------------------------------------------------- f-2: I_da's encoder call and unit splice
+def ida_corrupt(y, frame_start: int, mask_size: int):
+    """`y_inpainting = (y + 1e-6) * mask` with mask = 0 on [frame_start, frame_start + mask_size) (I_da/scripts/
+    inpainting.py:186-192).  `y` is what `sf.read` returns -- float64 -- so the sum is formed in float64; the float32 cast
+    happens in `get_feats` (`torch.from_numpy(x).float()`, I_da/src/hubert_feature_reader.py:50).  -> float64 numpy."""
+    import numpy as np
+
+    y = np.asarray(y, dtype=np.float64)
+    mask = np.ones_like(y)
+    mask[frame_start: frame_start + mask_size] = 0
+    return (y + 1e-6) * mask
+
+
+def hubert_get_feats(sd, arch, signal, output_layer: int, normalize: bool = True, prefix: str = "base_model.") -> torch.Tensor:
+    """`HubertFeatureReader.get_feats(None, signal=...)` (I_da/src/hubert_feature_reader.py:44-67) for ONE clip (numpy,
+    any float dtype): `.float()` (:50), `F.layer_norm(x, x.shape)` when task.cfg.normalize (:53-54; eps 1e-5, statistics over
+    the whole clip), `model.extract_features(source, padding_mask=None, mask=False, output_layer=L)` (:60-65) -> (T, H).
+    The clip is shorter than `max_chunk` (1.6 M samples, :13,58), so there is one chunk.
+    `extract_features` is fairseq's (`fairseq.models.hubert.HubertModel.extract_features` -> `forward(features_only=True)`
+    -> `TransformerEncoder.extract_features(x, padding_mask, tgt_layer=L-1)`): NOT in this image and no version is pinned by
+    the reference (requirements.txt omits fairseq).  Its published algorithm, restated: conv feature extractor -> transpose
+    -> LayerNorm(512) -> post_extract_proj -> x + GELU(pos_conv(x)) -> [LayerNorm unless layer_norm_first] -> layers
+    0..L-1, returning layer L-1's output; the encoder's final LayerNorm (layer_norm_first checkpoints) is applied only when
+    NO layer is requested.  (Newer fairseq pads T to a multiple of 2 with masked frames before the layers and strips them
+    afterwards: no effect on the real frames.)  That is `hubert_encode(..., output_layer=L)` above -- the transformers port of
+    the same architecture, whose `hidden_states[L]` pins it (tests/golden/hidden_layers.npz)."""
+    x = torch.as_tensor(signal).float()
+    if normalize:
+        x = F.layer_norm(x, x.shape)
+    return hubert_encode(sd, arch, x.view(1, -1), prefix, None, None, output_layer)[0]
+
+
+def code_splice(code: torch.Tensor, code_inpainting: torch.Tensor, frame_start: int, mask_size: int, code_hop_size: int = 320) -> torch.Tensor:
+    """I_da/scripts/inpainting.py:209-214 on 1-D unit series: the corrupted clip's units survive only inside the mask."""
+    out = code_inpainting.clone()
+    out[: frame_start // code_hop_size] = code[: frame_start // code_hop_size]
+    out[(frame_start + mask_size) // code_hop_size:] = code[(frame_start + mask_size) // code_hop_size:]
+    return out
+
+
+def ida_match_lengths(n_audio: int, n_code: int, n_f0: int, code_hop: int = 320, f0_hop: int = 80):
+    """The length bookkeeping of `inpainting()` (I_da/scripts/inpainting.py:219-255): `match_length([(audio, 1), (audio_mask, 1),
+    (code, code_hop), (fo, f0_hop)])` (I_da/src/multiseries.py:5-73: units of lcm(hops) samples, the minimum count over the
+    series) followed by the removal of `audio % (16 * 80)` samples' worth from the tail of every series.  NOTE that the
+    script matches `code` but NOT `code_inpainting` (:219-227), which keeps its full length until the tail removal (:253).
+    -> (audio samples, code frames, code_inpainting frames, f0 frames)."""
+    import math
+
+    unit = math.lcm(1, 1, code_hop, f0_hop)
+    n_unit = min(n_audio // unit, n_code // (unit // code_hop), n_f0 // (unit // f0_hop))
+    a, c, ci, f = n_unit * unit, n_unit * (unit // code_hop), n_code, n_unit * (unit // f0_hop)
+    to_remove = a % (16 * 80)
+    assert to_remove % code_hop == 0                                                         # :245
+    if to_remove:
+        a, c, ci, f = a - to_remove, c - to_remove // code_hop, ci - to_remove // code_hop, f - to_remove // 80
+    return a, c, ci, f
+
+
+def ida_inpaint(hubert_sd, harch, gen_sd, varch, centroids, emb_c, emb_p, f0_state, wave, frame_start: int, mask_size: int, f0,
+                spk_emb=None, output_layer: int = 6, normalize: bool = True, code_hop: int = 320):
+    """`inpainting()` of I_da/scripts/inpainting.py:151-266 for ONE clip, from `audio_gt` to the two generator outputs:
+    corruption (:186-192), HuBERT features of both signals (:195-198), k-means units (:204-205), unit splice (:209-214),
+    length matching (:219-255), `generate` x 2 (:258-259; the CodeGenerator's front + F0 VQ-VAE + unit HiFi-GAN).
+    wave: float64 / float32 numpy (N,); f0: (1, Tf0) normalised F0 track (YAAPT + normalize_nonzero, :216-218, is third-party CPU
+    code outside the path and enters as an input); spk_emb (E,) or None.  Returns dict(code, code_inpainting, audio_gen,
+    audio_inp) with float32 waveforms (before `generate`'s int16 cast)."""
+    import numpy as np
+
+    y = np.asarray(wave)
+    y_inp = ida_corrupt(y, frame_start, mask_size)
+    with torch.no_grad():
+        feats = hubert_get_feats(hubert_sd, harch, y, output_layer, normalize)
+        feats_inp = hubert_get_feats(hubert_sd, harch, y_inp, output_layer, normalize)
+        code = kmeans_assign(feats, centroids)
+        code_inp = code_splice(code, kmeans_assign(feats_inp, centroids), frame_start, mask_size, code_hop)
+        f0t = torch.as_tensor(f0, dtype=torch.float32).reshape(1, 1, -1)
+        _, nc, nci, nf = ida_match_lengths(len(y), code.numel(), f0t.shape[-1], code_hop)
+        f0t = f0t[..., :nf]
+        z_p = f0_vq_codes(f0_encoder_forward(f0_state, f0t), f0_state["vq.level_blocks.0.k"])
+        spk = None if spk_emb is None else torch.as_tensor(spk_emb, dtype=torch.float32).reshape(1, -1)
+        outs = []
+        for c in (code[:nc], code_inp[:nci]):
+            x = code_generator_front(c[None], emb_c, z_p, emb_p, spk)
+            outs.append(generator_forward(gen_sd, varch, x)[0, 0])
+    return {"code": code[:nc], "code_inpainting": code_inp[:nci], "feats": feats, "feats_inpainting": feats_inp,
+            "audio_gen": outs[0], "audio_inp": outs[1]}
 
 
 def custom_model_forward(sd, arch, x_norm: torch.Tensor, taps: Optional[dict] = None,

@@ -577,6 +577,10 @@ const float* wf(const si_ctx* ctx, size_t off) { return reinterpret_cast<const f
 
 }  // namespace
 
+static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len, const int32_t* valid_len,
+                      int normalize, float norm_eps, const double* pre_add, int output_layer, int B, int N, float* out_feats, float* out_hidden,
+                      void* workspace, size_t workspace_bytes, si_stream_t stream);
+
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -672,8 +676,42 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
 int si_hubert_forward_padded(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len, const int32_t* valid_len,
                              int normalize, int B, int N, float* out_feats, void* workspace, size_t workspace_bytes, si_stream_t stream) {
     if (!ctx) return SI_EINVAL;
+    if (!out_feats) return si_fail(ctx, SI_EINVAL, "si_hubert_forward: NULL / empty argument");
+    return hubert_run(ctx, wav, mask_start, mask_len, valid_len, normalize, 1e-7f, nullptr, 0, B, N, out_feats, nullptr, workspace,
+                      workspace_bytes, stream);
+}
+
+int si_hubert_extract_features(si_ctx* ctx, const si_extract_desc* x, const float* wav, const int32_t* mask_start, const int32_t* mask_len,
+                               const double* pre_mask_add, int B, int N, float* out_hidden, void* workspace, size_t workspace_bytes,
+                               si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!x || x->struct_size != (int32_t)sizeof(si_extract_desc)) return si_fail(ctx, SI_EINVAL, "si_hubert_extract_features: si_extract_desc size mismatch");
+    if (!out_hidden) return si_fail(ctx, SI_EINVAL, "si_hubert_extract_features: NULL output");
+    if (x->output_layer < 1 || x->output_layer > ctx->d.num_layers)
+        return si_fail(ctx, SI_EINVAL, "output_layer %d outside 1..%d", x->output_layer, ctx->d.num_layers);
+    if (x->normalize < 0 || x->normalize > 2) return si_fail(ctx, SI_EINVAL, "normalize mode %d unknown (0 none, 1 processor, 2 layer_norm)", x->normalize);
+    return hubert_run(ctx, wav, mask_start, mask_len, nullptr, x->normalize != 0, x->normalize == 2 ? 1e-5f : 1e-7f, pre_mask_add,
+                      x->output_layer, B, N, nullptr, out_hidden, workspace, workspace_bytes, stream);
+}
+
+int si_code_splice(si_ctx* ctx, const int64_t* code_clean, const int64_t* code_masked, const int32_t* first, const int32_t* last, int B, int T,
+                   int64_t* out, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!code_clean || !code_masked || !first || !last || !out || B <= 0 || T <= 0) return si_fail(ctx, SI_EINVAL, "si_code_splice: NULL / empty argument");
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    return si_launch_code_splice(ctx, code_clean, code_masked, first, last, B, T, out, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"
+
+// The encoder.  output_layer = 0: all layers [+ the stable flavour's final LayerNorm] + final_layers -> out_feats (B, T, codebook_dim).
+// output_layer = L >= 1: stop after L transformer layers and copy the hidden state (the residual stream in the pre-LN flavour, the
+// layer's output LayerNorm in the post-LN one) to out_hidden (B, T, H) -- fairseq's extract_features(output_layer = L).
+static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len, const int32_t* valid_len,
+                      int normalize, float norm_eps, const double* pre_add, int output_layer, int B, int N, float* out_feats, float* out_hidden,
+                      void* workspace, size_t workspace_bytes, si_stream_t stream) {
     if (!ctx->weights_ready) return si_fail(ctx, SI_ESTATE, "si_hubert_forward before weights were loaded");
-    if (!wav || !out_feats || !workspace || B <= 0) return si_fail(ctx, SI_EINVAL, "si_hubert_forward: NULL / empty argument");
+    if (!wav || !workspace || B <= 0) return si_fail(ctx, SI_EINVAL, "si_hubert_forward: NULL / empty argument");
     const si_model_desc& d = ctx->d;
     const Layout& L = ctx->lay;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -718,7 +756,7 @@ int si_hubert_forward_padded(si_ctx* ctx, const float* wav, const int32_t* mask_
 
     int rc;
     // A0 + A1: normalise fused into conv0
-    WaveNormParams wp{wav, mask_start, mask_len, B, N, e.L[1], d.conv_dim[0], d.conv_kernel[0], d.conv_stride[0], normalize, valid_len};
+    WaveNormParams wp{wav, mask_start, mask_len, B, N, e.L[1], d.conv_dim[0], d.conv_kernel[0], d.conv_stride[0], normalize, valid_len, norm_eps, pre_add};
     if ((rc = si_launch_wave_stats(ctx, wp, stats, st))) return rc;
     if (valid_len && (rc = si_launch_frame_lengths(ctx, valid_len, B, d.num_conv, d.conv_kernel, d.conv_stride, e.T, vframes, st))) return rc;
     if (!d.feat_norm_layer) {
@@ -805,6 +843,12 @@ int si_hubert_forward_padded(si_ctx* ctx, const float* wav, const int32_t* mask_
             if ((rc = linear(ctx, Wl.ffn1, h2, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16))) return rc;
             if ((rc = linear(ctx, Wl.ffn2, ffn, h, BT, SI_ACT_NONE, h, st, ffn16))) return rc;
         }
+        if (output_layer == l + 1) {
+            // fairseq `extract_features(output_layer = L)` (I_da/src/hubert_feature_reader.py:60-65): the loop stops after layer
+            // L - 1 and returns its output; the pre-LN flavour's final LayerNorm is applied only when no layer was asked for
+            SI_HIP_CHECK(hipMemcpyAsync(out_hidden, h, (size_t)BT * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+            return SI_OK;
+        }
     }
     if (d.stable_layer_norm) {
         if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, L.enc_ln_g), wf(ctx, L.enc_ln_b), h2, BT, H, eps, 0, st))) return rc;
@@ -815,6 +859,8 @@ int si_hubert_forward_padded(si_ctx* ctx, const float* wav, const int32_t* mask_
     if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, L.head_ln_g), wf(ctx, L.head_ln_b), h2, BT, H, 1e-5f, 0, st))) return rc;
     return linear(ctx, L.head, h2, out_feats, BT, SI_ACT_NONE, nullptr, st);
 }
+
+extern "C" {
 
 int si_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, const int32_t* frame_pos, int Lm, float* mel, int Tm,
                        int64_t* labels, si_stream_t stream) {

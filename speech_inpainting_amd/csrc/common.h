@@ -100,6 +100,10 @@ struct WaveNormParams {           // A0 + A1 (group-norm flavour)
     const int32_t* valid_len;     // (B) or null: samples of each right-padded clip that are real; the rest is padding
                                   // (statistics over the real samples only, padding reads as 0 AFTER the normalisation:
                                   // transformers/models/wav2vec2/feature_extraction_wav2vec2.py:88-91)
+    float norm_eps;               // variance epsilon of the normalisation: 1e-7 (HF processor) / 1e-5 (F.layer_norm(x, x.shape),
+                                  // I_da/src/hubert_feature_reader.py:53-54)
+    const double* pre_add;        // (B) or null: value added to every sample BEFORE the zero mask, in fp64, rounded to fp32
+                                  // once -- `(y + 1e-6) * mask` on the float64 clip (I_da/scripts/inpainting.py:187-192)
 };
 
 int si_launch_wave_stats(si_ctx* ctx, const WaveNormParams& p, double* stats /*B*2: mean, rstd*/, hipStream_t st);
@@ -136,6 +140,10 @@ int si_launch_zero_padded_rows(si_ctx* ctx, float* x, int B, int T, int H, const
 int si_launch_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,
                               const float* cb_centered /*K x D*/, const float* cb_raw /*K x D*/,
                               const float* cb_rnorm /*K*/, int K, float* mel, int Tm, int64_t* labels, hipStream_t st);
+
+// out[b][t] = (t < first[b] || t >= last[b]) ? clean[b][t] : masked[b][t]  (I_da/scripts/inpainting.py:209-214)
+int si_launch_code_splice(si_ctx* ctx, const int64_t* clean, const int64_t* masked, const int32_t* first, const int32_t* last, int B, int T,
+                          int64_t* out, hipStream_t st);
 
 // mel[b, :, pos_b + j] = cb_raw[labels[b, j]] (the expected_inpaint splice, I_ea/predict.py:177-189)
 int si_launch_codebook_gather(si_ctx* ctx, const int64_t* labels, int B, int D, const int32_t* frame_pos, int Lm,

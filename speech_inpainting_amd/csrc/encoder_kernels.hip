@@ -36,8 +36,14 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// One raw sample as the normalisation sees it: [+ pre_add in fp64, rounded once], then the zero mask.
+__device__ __forceinline__ float masked_sample(float v, int i, int ms, int ml, bool has_add, double add) {
+    if (i >= ms && i < ms + ml) return 0.f;
+    return has_add ? (float)((double)v + add) : v;
+}
+
 // ------------------------------------------------------------------------------------------------ A0
-// stats[b] = {mean, 1/sqrt(var + 1e-7)} of the zero-masked clip, accumulated in fp64.
+// stats[b] = {mean, 1/sqrt(var + eps)} of the zero-masked clip, accumulated in fp64.
 __global__ __launch_bounds__(1024) void wave_stats_kernel(WaveNormParams p, double* __restrict__ stats) {
     const int b = blockIdx.x;
     if (!p.normalize) {
@@ -48,6 +54,8 @@ __global__ __launch_bounds__(1024) void wave_stats_kernel(WaveNormParams p, doub
     const int ms = p.mask_start ? p.mask_start[b] : 0;
     const int ml = p.mask_len ? p.mask_len[b] : 0;
     const int nv = p.valid_len ? min(max(p.valid_len[b], 1), p.N) : p.N;      // real samples of a right-padded clip
+    const bool has_add = p.pre_add != nullptr;
+    const double add = has_add ? p.pre_add[b] : 0.0;
     double s = 0.0, ss = 0.0;
     // 16 bytes per lane and four loads in flight per thread (one workgroup walks a whole clip: with 4-byte loads in a
     // dependent loop the launch was a 35 us latency chain); the tail and unaligned clips take the scalar loop
@@ -58,14 +66,13 @@ __global__ __launch_bounds__(1024) void wave_stats_kernel(WaveNormParams p, doub
         const f32x4 q = *reinterpret_cast<const f32x4*>(x + i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float v = (i + e >= ms && i + e < ms + ml) ? 0.f : q[e];
+            const float v = masked_sample(q[e], i + e, ms, ml, has_add, add);
             s += v;
             ss += (double)v * v;
         }
     }
     for (int i = nv4 + threadIdx.x; i < nv; i += blockDim.x) {
-        float v = x[i];
-        if (i >= ms && i < ms + ml) v = 0.f;
+        const float v = masked_sample(x[i], i, ms, ml, has_add, add);
         s += v;
         ss += (double)v * v;
     }
@@ -82,15 +89,13 @@ __global__ __launch_bounds__(1024) void wave_stats_kernel(WaveNormParams p, doub
         double var = SS / nv - mean * mean;
         if (var < 0) var = 0;
         stats[2 * b] = mean;
-        stats[2 * b + 1] = 1.0 / sqrt(var + 1e-7);
+        stats[2 * b + 1] = 1.0 / sqrt(var + (double)p.norm_eps);
     }
 }
 
-__device__ __forceinline__ float load_norm(const float* x, int i, int ms, int ml, float mean, float rstd, int nv) {
+__device__ __forceinline__ float load_norm(const float* x, int i, int ms, int ml, float mean, float rstd, int nv, bool has_add, double add) {
     if (i >= nv) return 0.f;                                         // padding value, applied after the normalisation
-    float v = x[i];
-    if (i >= ms && i < ms + ml) v = 0.f;
-    return (v - mean) * rstd;
+    return (masked_sample(x[i], i, ms, ml, has_add, add) - mean) * rstd;
 }
 
 // partials[b][chunk][NP]: NP = K + K(K+1)/2 lag sums of the normalised clip over the chunk's conv positions.
@@ -110,7 +115,9 @@ __global__ __launch_bounds__(256) void conv0_lagsums_kernel(WaveNormParams p, co
     const float* x = p.wav + (long)b * p.N;
     const int win = (nt - 1) * S + K;
     const int nv = p.valid_len ? min(max(p.valid_len[b], 1), p.N) : p.N;
-    for (int i = threadIdx.x; i < win; i += 256) xs[i] = load_norm(x, t0 * S + i, ms, ml, mean, rstd, nv);
+    const bool has_add = p.pre_add != nullptr;
+    const double add = has_add ? p.pre_add[b] : 0.0;
+    for (int i = threadIdx.x; i < win; i += 256) xs[i] = load_norm(x, t0 * S + i, ms, ml, mean, rstd, nv, has_add, add);
     __syncthreads();
     __shared__ double part[2][160];
     const int pr = threadIdx.x & 127, half = threadIdx.x >> 7;
@@ -186,7 +193,9 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(WaveNormParams p, cons
     const float* x = p.wav + (long)b * p.N;
     const int win = (nt - 1) * S + K;
     const int nv = p.valid_len ? min(max(p.valid_len[b], 1), p.N) : p.N;
-    for (int i = threadIdx.x; i < win; i += 256) xs[i] = load_norm(x, t0 * S + i, ms, ml, mean, rstd, nv);
+    const bool has_add = p.pre_add != nullptr;
+    const double add = has_add ? p.pre_add[b] : 0.0;
+    for (int i = threadIdx.x; i < win; i += 256) xs[i] = load_norm(x, t0 * S + i, ms, ml, mean, rstd, nv, has_add, add);
     __syncthreads();
     const int tpr = C / 4;                       // threads per output row (float4 of channels each)
     const int rpp = 256 / tpr;                   // rows per pass
@@ -962,6 +971,28 @@ int si_launch_kmeans_assign(si_ctx* ctx, const float* x, long rows, int D, const
     if (rows <= 0) return SI_OK;
     si_prof_begin(ctx, "kmeans_assign", 2.0 * rows * (double)K * D, 4.0 * rows * D, st);
     hipLaunchKernelGGL(kmeans_assign_kernel, dim3((unsigned)rows), dim3(256), (size_t)D * sizeof(float), st, x, D, cent, K, labels, dist);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
+// I_da code splice (I_da/scripts/inpainting.py:209-214): the masked stream's units survive only inside the mask,
+// `code_inpainting[: fs // hop] = code[: fs // hop]; code_inpainting[(fs + ms) // hop :] = code[(fs + ms) // hop :]`.
+__global__ __launch_bounds__(256) void code_splice_kernel(const int64_t* __restrict__ clean, const int64_t* __restrict__ masked,
+                                                          const int32_t* __restrict__ first, const int32_t* __restrict__ last, int T,
+                                                          int64_t* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const long i = (long)b * T + t;
+    out[i] = (t < first[b] || t >= last[b]) ? clean[i] : masked[i];
+}
+
+int si_launch_code_splice(si_ctx* ctx, const int64_t* clean, const int64_t* masked, const int32_t* first, const int32_t* last, int B, int T,
+                          int64_t* out, hipStream_t st) {
+    if (B <= 0 || T <= 0) return SI_OK;
+    si_prof_begin(ctx, "code_splice", 0.0, 24.0 * B * T, st);
+    hipLaunchKernelGGL(code_splice_kernel, dim3((T + 255) / 256, B), dim3(256), 0, st, clean, masked, first, last, T, out);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

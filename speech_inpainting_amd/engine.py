@@ -28,6 +28,26 @@ def mask_samples_from_frames(frame_pos: int, frame_len: int):
     return s, max(e - s, 0)
 
 
+def ida_match_lengths(n_audio: int, n_code: int, n_f0: int, code_hop: int = 320, f0_hop: int = 80):
+    """Length bookkeeping of I_da's `inpainting()` (I_da/scripts/inpainting.py:219-255): `match_length` over (audio, 1),
+    (audio_mask, 1), (code, code_hop), (fo, f0_hop) -- whole units of lcm(hops) samples, the minimum count over the series
+    (I_da/src/multiseries.py:33-52) -- then `audio % (16 * 80)` samples' worth removed from every tail (:243-255).  The script
+    matches `code` but not `code_inpainting`, which is only tail-trimmed.  -> (audio samples, code frames, code_inpainting
+    frames, f0 frames)."""
+    import math
+    unit = math.lcm(code_hop, f0_hop)
+    n_unit = min(n_audio // unit, n_code // (unit // code_hop), n_f0 // (unit // f0_hop))
+    a, c, ci, f = n_unit * unit, n_unit * (unit // code_hop), n_code, n_unit * (unit // f0_hop)
+    to_remove = a % (16 * 80)
+    if to_remove % code_hop:
+        raise AssertionError(f"to_remove={to_remove} is not a multiple of code_hop_size={code_hop} (I_da/scripts/inpainting.py:245)")
+    if to_remove:
+        a, c, ci, f = a - to_remove, c - to_remove // code_hop, ci - to_remove // code_hop, f - to_remove // 80
+    if min(c, ci, f) <= 0:
+        raise ValueError(f"clip too short for I_da's length matching: audio {n_audio}, code {n_code}, f0 {n_f0} frames")
+    return a, c, ci, f
+
+
 class InpaintingEngine:
     """One model pair (HuBERT + head, codebook, HiFi-GAN generator) resident on one GPU."""
 
@@ -40,7 +60,16 @@ class InpaintingEngine:
         self._resamplers = {}
 
     # ---- weights
-    def load_state(self, hubert_sd: Mapping[str, torch.Tensor], gen_sd: Mapping[str, torch.Tensor], codebook: torch.Tensor):
+    def load_state(self, hubert_sd: Mapping[str, torch.Tensor], gen_sd: Mapping[str, torch.Tensor], codebook: Optional[torch.Tensor] = None):
+        """hubert_sd: a CustomModel state dict, or the encoder alone (a HuggingFace directory / an I_da feature reader has no
+        `final_layers`: they are then initialised as the reference's constructor initialises them, I_ea/model.py:75-78).
+        codebook (K, codebook_dim) or None (I_da: the unit codebook lives in HuBERT feature space and is passed per call)."""
+        from .checkpoint import fresh_final_layers, normalize_hubert_keys
+        hubert_sd = normalize_hubert_keys(hubert_sd)
+        if "final_layers.1.weight" not in hubert_sd:
+            hubert_sd.update(fresh_final_layers(self.harch))
+        if codebook is None:
+            codebook = torch.zeros(self.ctx.desc.num_clusters, self.harch.codebook_dim)
         blob, index = flatten_checkpoint(hubert_sd, gen_sd, codebook)
         self.ctx.load_weights(blob, index)
         return self
@@ -57,6 +86,56 @@ class InpaintingEngine:
                normalize: bool = True, valid_len: Optional[torch.Tensor] = None) -> torch.Tensor:
         """valid_len (B,) int32: real samples per clip of a RIGHT-PADDED batch (the reference's attention_mask.sum(-1))."""
         return self.ctx.hubert_forward(wave16, mask_start, mask_len, normalize, valid_len)
+
+    def extract_features(self, wave16: torch.Tensor, output_layer: int, normalize="layer_norm",
+                         mask_start: Optional[torch.Tensor] = None, mask_len: Optional[torch.Tensor] = None,
+                         pre_mask_add: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`HubertFeatureReader.get_feats` for a batch (I_da/src/hubert_feature_reader.py:44-67): (B, N) raw clips ->
+        (B, T, H) hidden state after `output_layer` transformer layers; see NativeContext.hubert_extract_features."""
+        return self.ctx.hubert_extract_features(wave16, output_layer, normalize, mask_start, mask_len, pre_mask_add)
+
+    def ida_inpaint_batch(self, wave16: torch.Tensor, frame_start, mask_size: int, centroids: torch.Tensor,
+                          generator: "CodeGenerator", f0: torch.Tensor, emb: Optional[torch.Tensor] = None,
+                          output_layer: int = 6, normalize: bool = True, code_hop_size: int = 320, f0_hop: int = 80) -> Dict[str, torch.Tensor]:
+        """`inpainting()` of I_da/scripts/inpainting.py:151-266 for a batch of equal-length clips, on this GPU end to end:
+        corruption `(y + 1e-6) * mask` (:186-192) fused into the encoder's first conv, HuBERT features of the clean and the
+        corrupted clips at `output_layer` (:195-198; ONE encoder pass over 2B clips), k-means units (:204-205, GPU instead of
+        sklearn on the host), unit splice (:209-214), the script's length bookkeeping (:219-255), and `generate` for both unit
+        series (:258-259; one CodeGenerator pass over 2B series).
+        wave16 (B, N) fp32 at 16 kHz; frame_start int or (B,) int tensor (samples; the script uses 1.5 s, :188); mask_size
+        samples; centroids (K, H) the k-means model's `cluster_centers_`; generator a `CodeGenerator` over this engine (with
+        its `F0Quantizer`); f0 (B, 1, Tf0) the normalised F0 track (YAAPT + normalize_nonzero, :216-217, is third-party CPU code
+        outside the path); emb (B, E) speaker embedding or None.
+        -> dict(code (B, F), code_inpainting (B, F'), audio_gen (B, F * hop), audio_inp (B, F' * hop), feats (2B, T, H))."""
+        dev = self.device
+        B, N = wave16.shape
+        fs = torch.as_tensor(frame_start, dtype=torch.int32, device=dev).reshape(-1).expand(B).contiguous()
+        zi = torch.zeros(B, dtype=torch.int32, device=dev)
+        ms = torch.cat([zi, fs])
+        ml = torch.cat([zi, torch.full((B,), int(mask_size), dtype=torch.int32, device=dev)])
+        add = torch.cat([torch.zeros(B, dtype=torch.float64, device=dev), torch.full((B,), 1e-6, dtype=torch.float64, device=dev)])
+        both = torch.cat([wave16, wave16]).contiguous()
+        hid = self.extract_features(both, output_layer, "layer_norm" if normalize else None, ms, ml, add)       # (2B, T, H)
+        T, H = hid.shape[1], hid.shape[2]
+        units = self.ctx.kmeans_assign(hid.reshape(2 * B * T, H), centroids.to(dev, torch.float32).contiguous()).reshape(2 * B, T)
+        code = units[:B].contiguous()
+        first = torch.div(fs, code_hop_size, rounding_mode="floor").to(torch.int32)
+        last = torch.div(fs + int(mask_size), code_hop_size, rounding_mode="floor").to(torch.int32)
+        code_inp = self.ctx.code_splice(code, units[B:].contiguous(), first, last)
+        _, nc, nci, nf = ida_match_lengths(N, T, f0.shape[-1], code_hop_size, f0_hop)
+        f0 = f0.to(dev, torch.float32)[..., :nf].contiguous()
+        if generator.f0_quantizer is None:
+            raise ValueError("ida_inpaint_batch: the CodeGenerator needs its F0Quantizer (the fixed F0 VQ-VAE, I_da/src/model.py:160-166)")
+        z_p = generator.f0_quantizer(f0)                                               # the same F0 track conditions both outputs
+        code, code_inp = code[:, :nc].contiguous(), code_inp[:, :nci].contiguous()
+        if nc == nci:
+            wav = generator(code=torch.cat([code, code_inp]), f0_code=torch.cat([z_p, z_p]),
+                            emb=None if emb is None else torch.cat([emb, emb]))[:, 0]
+            gen, inp = wav[:B], wav[B:]
+        else:                                   # the script trims `code` but not `code_inpainting` (:219-227): two shapes
+            gen = generator(code=code, f0_code=z_p, emb=emb)[:, 0]
+            inp = generator(code=code_inp, f0_code=z_p, emb=emb)[:, 0]
+        return {"code": code, "code_inpainting": code_inp, "audio_gen": gen, "audio_inp": inp, "feats": hid}
 
     def splice(self, feats: torch.Tensor, frame_pos: torch.Tensor, lm: int, mel: torch.Tensor) -> torch.Tensor:
         return self.ctx.codebook_splice(feats, frame_pos, lm, mel)

@@ -21,7 +21,7 @@ SI_MATH = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, "fp16": 3, "f16": 3}
 SI_MAX_CONV, SI_MAX_UPS, SI_MAX_RB, SI_MAX_DIL = 8, 8, 4, 4
 
 EXPORTS = ["si_version", "si_create", "si_destroy", "si_last_error", "si_load_weights", "si_alloc_weights",
-           "si_weights_device_ptr", "si_workspace_bytes", "si_hubert_forward", "si_hubert_forward_padded", "si_codebook_splice",
+           "si_weights_device_ptr", "si_workspace_bytes", "si_hubert_forward", "si_hubert_forward_padded", "si_hubert_extract_features", "si_code_splice", "si_codebook_splice",
            "si_codebook_splice_labels", "si_codebook_metrics", "si_kmeans_assign", "si_mel_metrics", "si_sisdr", "si_unit_frontend",
            "si_f0_encoder_weight_floats", "si_f0_encoder_frames", "si_f0_encoder_workspace_bytes", "si_f0_encoder_forward",
            "si_resample_poly", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
@@ -48,6 +48,14 @@ class F0EncDesc:
     def down_kernel(self):
         s = self.stride_t
         return (2 * s, s // 2) if s % 2 == 0 else (2 * s + 1, s // 2 + 1)          # jukebox.py:54-57
+
+
+class ExtractDesc(C.Structure):
+    """Mirror of si_extract_desc."""
+    _fields_ = [("struct_size", C.c_int32), ("output_layer", C.c_int32), ("normalize", C.c_int32), ("reserved", C.c_int32)]
+
+
+NORMALIZE_MODES = {None: 0, False: 0, "none": 0, "processor": 1, True: 1, "layer_norm": 2}
 
 
 class ProfileEntry(C.Structure):
@@ -144,6 +152,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.si_workspace_bytes.argtypes = [vp, i32, i32, i32, C.POINTER(sz)]
     lib.si_hubert_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_hubert_forward_padded.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
+    lib.si_hubert_extract_features.argtypes = [vp, C.POINTER(ExtractDesc), vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
+    lib.si_code_splice.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp]
     lib.si_codebook_splice.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp]
     lib.si_codebook_splice_labels.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp]
     lib.si_codebook_metrics.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp]
@@ -290,6 +300,46 @@ class NativeContext:
         self._check(self.lib.si_hubert_forward_padded(self._h, _ptr(wav), _ptr(mask_start), _ptr(mask_len), _ptr(valid_len),
                                                       int(normalize), B, N, _ptr(out), _ptr(ws), ws.numel(), self._stream()),
                     "si_hubert_forward_padded")
+        return out
+
+    def hubert_extract_features(self, wav: torch.Tensor, output_layer: int, normalize="layer_norm",
+                                mask_start: Optional[torch.Tensor] = None, mask_len: Optional[torch.Tensor] = None,
+                                pre_mask_add: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """wav (B, N) fp32 -> (B, T, H) fp32: the hidden state after `output_layer` transformer layers (fairseq
+        `extract_features(output_layer=...)`, I_da/src/hubert_feature_reader.py:60-65).  normalize: "layer_norm" (I_da:
+        F.layer_norm over the clip, eps 1e-5), "processor" (I_ea: eps 1e-7) or None.  mask_start / mask_len int32 (B) and
+        pre_mask_add float64 (B): `(y + add) * mask` in front of it (I_da/scripts/inpainting.py:186-192)."""
+        assert wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2 and wav.is_contiguous()
+        B, N = wav.shape
+        T = self.num_frames(N)
+        if T < 1:
+            raise ValueError(f"clip of {N} samples is too short")
+        for m in (mask_start, mask_len):
+            assert m is None or (m.is_cuda and m.dtype == torch.int32 and m.numel() == B and m.is_contiguous())
+        assert pre_mask_add is None or (pre_mask_add.is_cuda and pre_mask_add.dtype == torch.float64 and pre_mask_add.numel() == B
+                                        and pre_mask_add.is_contiguous())
+        if normalize not in NORMALIZE_MODES:
+            raise ValueError(f"normalize={normalize!r}: expected one of {list(NORMALIZE_MODES)}")
+        x = ExtractDesc(C.sizeof(ExtractDesc), int(output_layer), NORMALIZE_MODES[normalize], 0)
+        out = torch.empty(B, T, self.desc.hidden_size, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, N, 0)
+        self._check(self.lib.si_hubert_extract_features(self._h, C.byref(x), _ptr(wav), _ptr(mask_start), _ptr(mask_len),
+                                                        _ptr(pre_mask_add), B, N, _ptr(out), _ptr(ws), ws.numel(), self._stream()),
+                    "si_hubert_extract_features")
+        return out
+
+    def code_splice(self, code_clean: torch.Tensor, code_masked: torch.Tensor, first: torch.Tensor, last: torch.Tensor) -> torch.Tensor:
+        """(B, T) int64 unit series of the clean and the corrupted clip -> the corrupted clip's units inside frames
+        [first[b], last[b]), the clean clip's elsewhere (I_da/scripts/inpainting.py:209-214)."""
+        for c in (code_clean, code_masked):
+            assert c.is_cuda and c.dtype == torch.int64 and c.dim() == 2 and c.is_contiguous()
+        assert code_clean.shape == code_masked.shape
+        B, T = code_clean.shape
+        for m in (first, last):
+            assert m.is_cuda and m.dtype == torch.int32 and m.numel() == B and m.is_contiguous()
+        out = torch.empty_like(code_masked)
+        self._check(self.lib.si_code_splice(self._h, _ptr(code_clean), _ptr(code_masked), _ptr(first), _ptr(last), B, T, _ptr(out),
+                                            self._stream()), "si_code_splice")
         return out
 
     def codebook_splice(self, feats: torch.Tensor, frame_pos: torch.Tensor, lm: int, mel: torch.Tensor) -> torch.Tensor:

@@ -94,6 +94,16 @@ def synth_hubert_state(arch: HubertArch, seed: int = DEFAULT_SEED, pos_conv_styl
     return sd
 
 
+def centre_head(sd, vbar: torch.Tensor):
+    """A copy of a CustomModel state dict whose head output is shifted by -vbar (`final_layers.1.bias -= vbar`).  With random
+    weights every encoder frame maps to nearly the same 80-dim vector, so the cosine arg-max against the centred centroids
+    (I_ea/loss_fn.py:44-47) returns one codeword for all frames; centring the head on the frames of interest -- what a head
+    trained against the centred centroids emits -- makes the label comparison a comparison of real decisions."""
+    out = OrderedDict(sd)
+    out["final_layers.1.bias"] = (sd["final_layers.1.bias"].float() - vbar.float()).contiguous()
+    return out
+
+
 def _wn_pair(g, shape, fan_in, gain):
     """weight_v ~ N(0, gain^2/fan_in); weight_g = ||v|| (dim=0 norm) * (1 + 0.1 n)."""
     v = _n(g, *shape, std=gain / math.sqrt(fan_in))

@@ -32,6 +32,8 @@ def load_case(name):
         mel=synth.synth_mel(meta["B"], meta["Tm"], 80, seed + 4),
         frame_pos=[int(p) for p in z["frame_pos"]],
     )
+    if "head_bias" in z.files:      # a fixture input: the head bias shifted so that the head output is centred on the masked frames
+        case["hsd"]["final_layers.1.bias"] = torch.from_numpy(z["head_bias"]).clone()
     probe = np.asarray([float(case["hsd"]["final_layers.1.weight"][0, 0]), float(case["gsd"]["conv_post.weight_v"][0, 0, 0]),
                         float(case["cb"][0, 0]), float(case["wave"][0, 100]), float(case["mel"][0, 0, 0])])
     # the fixture is only meaningful if the seeded generator reproduces the tensors it was made from

@@ -10,7 +10,7 @@ from tests.common import load_case, rms
 torch.set_num_threads(8)
 
 
-@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "tiny_blind", "base_4s", "large_4s"])
+@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "tiny_blind", "base_4s", "large_4s", "base_b4"])
 def test_oracle_matches_reference(name):
     c = load_case(name)
     m, z = c["meta"], c["z"]
@@ -29,7 +29,28 @@ def test_oracle_matches_reference(name):
     else:
         assert rms(out["wave"][:, :2048], z["wave_head"]) <= 1e-5
         assert rms(out["wave"][:, -2048:], z["wave_tail"]) <= 1e-5
+    if "wave_win" in z.files:        # the samples the spliced frames reach, per clip
+        for i, lo in enumerate(z["wave_win_lo"]):
+            assert rms(out["wave"][i, lo:lo + 16384], z["wave_win"][i]) <= 1e-5
     assert abs(rms(out["wave"]) - float(z["wave_rms"])) <= 1e-5
+
+
+def test_base_b4_fixture_discriminates():
+    """The base-size fixture whose labels are real decisions: >= 5 distinct codewords over its 4 x 10 masked frames, more than
+    one inside a clip, and fp32 cosine margins that are neither degenerate nor huge."""
+    import torch.nn.functional as F
+    c = load_case("base_b4")
+    z = c["z"]
+    labels = z["labels"]
+    assert labels.shape == (4, 10) and len(set(labels.reshape(-1).tolist())) >= 5
+    assert sum(len(set(row.tolist())) > 1 for row in labels) >= 2
+    feats = torch.from_numpy(z["feats"])
+    _, cc = R.codebook_tables(c["cb"])
+    v = torch.stack([feats[b, p:p + 10] for b, p in enumerate(c["frame_pos"])]).reshape(-1, 80)
+    sim = F.cosine_similarity(v[:, None, :], cc[None], dim=-1)
+    top2 = sim.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])
+    assert float(margin.min()) > 0 and float(margin.median()) < 0.2
 
 
 def test_normalize_matches_hf_processor():
@@ -133,6 +154,64 @@ def test_f0_vqvae_restatement_matches_the_reference_modules():
         codes = R.f0_vq_codes(h, sd["vq.level_blocks.0.k"])
         assert np.array_equal(codes.numpy(), z[f"codes_{T}"])                    # bit-exact indices
         assert len(set(z[f"codes_{T}"].reshape(-1).tolist())) >= 4               # the fixture exercises several bins
+
+
+def test_hidden_state_restatement_matches_transformers_hidden_states():
+    """Row f-2: the oracle's `hubert_get_feats` (fairseq `extract_features(output_layer=L)` restated; fairseq is absent) against
+    `transformers.HubertModel(output_hidden_states=True).hidden_states[L]` on inputs prepared by the reference's own
+    statements (tests/golden/hidden_layers.npz, tools/make_goldens.py::hidden_layer_cases)."""
+    import json
+    import os
+    import numpy as np
+    import torch
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch
+    from tests.common import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "hidden_layers.npz"))
+    meta = json.loads(str(z["meta"]))
+    for tag, harch in (("group", HubertArch.tiny(num_hidden_layers=3)),
+                       ("layer", HubertArch.tiny(num_hidden_layers=3, conv_bias=True, feat_extract_norm="layer", do_stable_layer_norm=True))):
+        hsd = synth.synth_hubert_state(harch, meta["seed"] + 60)
+        y = synth.synth_wave(2, meta["N"], meta["seed"] + 61).numpy().astype(np.float64)
+        for b in range(2):
+            for kind in ("clean", "masked"):
+                sig = y[b] if kind == "clean" else R.ida_corrupt(y[b], meta["frame_start"], meta["mask_size"])
+                for L in ((1, 2, 3) if tag == "group" else (1, 2)):
+                    with torch.no_grad():
+                        h = R.hubert_get_feats(hsd, harch, sig, L)
+                    ref = torch.from_numpy(z[f"{tag}_{kind}_{b}_L{L}"])
+                    assert h.shape == ref.shape
+                    assert float((h - ref).pow(2).mean().sqrt()) <= 2e-6 * float(ref.pow(2).mean().sqrt())
+    # the corruption: zero inside the span, y + 1e-6 (formed in float64) outside
+    y0 = y[0]
+    c = R.ida_corrupt(y0, 100, 50)
+    assert c.dtype == np.float64 and (c[100:150] == 0).all() and np.array_equal(c[:100], y0[:100] + 1e-6) and np.array_equal(c[150:], y0[150:] + 1e-6)
+
+
+def test_ida_length_bookkeeping_known_answers():
+    """`match_length` + the `% (16 * 80)` tail removal of I_da/scripts/inpainting.py:219-255, product (engine.ida_match_lengths) and
+    oracle, against a literal re-execution of the script's numpy statements."""
+    import numpy as np
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd.engine import ida_match_lengths
+
+    def script(n_audio, n_code, n_f0):
+        audio, code, code_inp, fo = np.zeros(n_audio), np.zeros(n_code), np.zeros(n_code), np.zeros((1, n_f0))
+        hops = [1, 1, 320, 80]
+        unit = np.lcm.reduce(hops)                                                  # multiseries.py:36
+        fpu = [unit // h for h in hops]
+        n_unit = min(s.shape[-1] // f for s, f in zip([audio, audio, code, fo], fpu))
+        audio, code, fo = audio[: n_unit * fpu[0]], code[: n_unit * fpu[2]], fo[..., : n_unit * fpu[3]]
+        to_remove = audio.shape[-1] % (16 * 80)                                     # inpainting.py:244
+        assert to_remove % 320 == 0
+        if to_remove:
+            audio, code, code_inp, fo = audio[:-to_remove], code[: -(to_remove // 320)], code_inp[: -(to_remove // 320)], fo[..., : -(to_remove // 80)]
+        return audio.shape[-1], code.shape[-1], code_inp.shape[-1], fo.shape[-1]
+
+    assert ida_match_lengths(64000, 199, 797) == (62720, 196, 196, 784)
+    for n_audio, n_code, n_f0 in ((64000, 199, 797), (64000, 199, 800), (160000, 499, 1997), (12800, 39, 157), (9600, 29, 117), (64000, 199, 700)):
+        assert ida_match_lengths(n_audio, n_code, n_f0) == R.ida_match_lengths(n_audio, n_code, n_f0) == script(n_audio, n_code, n_f0)
 
 
 def test_f0_encoder_restatement_shapes_and_known_answer():

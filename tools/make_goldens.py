@@ -125,7 +125,7 @@ def rms(t):
 
 
 def run_case(name, harch, varch, B, N, frame_pos, lm, K, out_dir, tmpdir, store_wave=True, blind=False,
-             legacy_pos=False):
+             legacy_pos=False, centre_head=False):
     from transformers import Wav2Vec2FeatureExtractor
     extend_mel = _extend_mel_call
     seed = synth.DEFAULT_SEED
@@ -143,6 +143,25 @@ def run_case(name, harch, varch, B, N, frame_pos, lm, K, out_dir, tmpdir, store_
     mel = synth.synth_mel(B, Tm, 80, seed + 4)
 
     model = build_reference_custom_model(harch, hsd_ref)
+    if centre_head:
+        # A randomly initialised encoder maps every frame to nearly the same vector (|mean| 7.6 against a frame-to-frame
+        # deviation of 0.2 in the 80-dim head output of base_4s), so the cosine arg-max picks ONE codeword for every frame and a
+        # label comparison decides nothing.  A trained head emits vectors around the CENTRED centroids (it is trained on
+        # cos(v, C - mean C), I_ea/loss_fn.py:29-47): shift the synthetic head's bias so that its output is centred over the
+        # masked frames of this batch.  The shifted bias is an INPUT of the fixture (stored as `head_bias`).
+        proc0 = Wav2Vec2FeatureExtractor(feature_size=1, sampling_rate=16000, padding_value=0.0, do_normalize=True, return_attention_mask=True)
+        vs = []
+        with torch.no_grad():
+            for b in range(B):
+                w = wave[b].numpy().copy()
+                p = int(frame_pos[b])
+                w[p * 320 + 80:(p + lm) * 320 + 79 - 80] = 0
+                tok = proc0(w, sampling_rate=16000, return_attention_mask=True, return_tensors="pt")
+                vs.append(model(tok.input_values, tok.attention_mask)[0][p:p + lm])
+        vbar = torch.cat(vs).mean(0)
+        hsd = synth.centre_head(hsd, vbar)
+        hsd_ref = hsd
+        model = build_reference_custom_model(harch, hsd_ref)
     gen = build_reference_generator(varch, gsd)
     loss = build_reference_loss(cb, tmpdir)
     proc = Wav2Vec2FeatureExtractor(feature_size=1, sampling_rate=16000, padding_value=0.0,
@@ -188,14 +207,24 @@ def run_case(name, harch, varch, B, N, frame_pos, lm, K, out_dir, tmpdir, store_
         weight_probe=np.asarray([float(hsd["final_layers.1.weight"][0, 0]), float(gsd["conv_post.weight_v"][0, 0, 0]),
                                  float(cb[0, 0]), float(wave[0, 100]), float(mel[0, 0, 0])], np.float64),
     )
-    if store_wave:
+    if centre_head:
+        rec["head_bias"] = hsd["final_layers.1.bias"].numpy()
+    if store_wave == "windows":
+        # the samples the spliced frames can reach (+- 4096 around the mask's span in the output) plus head and tail
+        rec["wave_head"] = wav[:, :2048].numpy()
+        rec["wave_tail"] = wav[:, -2048:].numpy()
+        lo = [max(0, int(p * 320 * 22050 / 16000) - 4096) for p in pos]
+        rec["wave_win_lo"] = np.asarray(lo, np.int64)
+        rec["wave_win"] = np.stack([wav[i, lo[i]:lo[i] + 16384].numpy() for i in range(B)])
+        rec["wave_sha"] = np.frombuffer(bytes.fromhex(sha(wav)), np.uint8)
+    elif store_wave:
         rec["wave"] = wav.numpy()
     else:
         rec["wave_head"] = wav[:, :2048].numpy()
         rec["wave_tail"] = wav[:, -2048:].numpy()
     np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
     print(f"{name}: feats rms {rms(feats):.4f}  wave rms {rms(wav):.4f} absmax {float(wav.abs().max()):.3f}  "
-          f"labels[0][:10] {pred[0][:10].tolist()}")
+          f"labels {pred[:, :10].tolist()}  distinct {len(set(pred.reshape(-1).tolist()))}")
 
 
 def extend_cases(out_dir):
@@ -344,6 +373,47 @@ def f0_vqvae_cases(out_dir):
     np.savez_compressed(os.path.join(out_dir, "f0_vqvae.npz"), **rec)
 
 
+def hidden_layer_cases(out_dir):
+    """I_da's encoder call (`HubertFeatureReader.get_feats`, I_da/src/hubert_feature_reader.py:44-67) needs fairseq, which is not
+    in this image.  The statements around the model ARE the reference's: `(y + 1e-6) * mask` on the float64 clip
+    (I_da/scripts/inpainting.py:186-192), `torch.from_numpy(x).float()`, `F.layer_norm(x, x.shape)`, `x.view(1, -1)`
+    (hubert_feature_reader.py:50-55).  The model call `extract_features(output_layer=L)` is taken from the transformers port of
+    the same architecture: `HubertModel(..., output_hidden_states=True).hidden_states[L]` is the state after L transformer
+    layers -- for L < num_layers in the pre-LN flavour WITHOUT the final LayerNorm, like fairseq's (the last entry has it
+    applied, so L = num_layers is stored for the post-LN flavour only)."""
+    import torch.nn.functional as F
+    from transformers import HubertModel
+    rec = {}
+    seed = synth.DEFAULT_SEED
+    N, fs, ms = 8000, 2560, 1920
+    for tag, harch in (("group", HubertArch.tiny(num_hidden_layers=3)),
+                       ("layer", HubertArch.tiny(num_hidden_layers=3, conv_bias=True, feat_extract_norm="layer", do_stable_layer_norm=True))):
+        hsd = synth.synth_hubert_state(harch, seed + 60)
+        m = HubertModel(_hf_config(harch))
+        missing, unexpected = m.load_state_dict({k[len("base_model."):]: v for k, v in hsd.items() if k.startswith("base_model.")}, strict=False)
+        assert not unexpected and all(k.endswith("masked_spec_embed") for k in missing), (missing, unexpected)
+        m.eval()
+        y = synth.synth_wave(2, N, seed + 61).numpy().astype(np.float64)              # what sf.read returns: float64
+        for b in range(2):
+            for kind in ("clean", "masked"):
+                sig = y[b]
+                if kind == "masked":
+                    mask = np.ones_like(sig)
+                    mask[fs:fs + ms] = 0                                               # inpainting.py:189-190
+                    sig = (sig + 1e-6) * mask                                          # :192
+                x = torch.from_numpy(sig).float()                                      # hubert_feature_reader.py:50
+                x = F.layer_norm(x, x.shape)                                           # :53-54
+                x = x.view(1, -1)                                                      # :55
+                with torch.no_grad():
+                    hs = m(x, output_hidden_states=True).hidden_states
+                for L in ((1, 2, 3) if tag == "group" else (1, 2)):
+                    rec[f"{tag}_{kind}_{b}_L{L}"] = hs[L][0].numpy()
+        rec[f"{tag}_probe"] = np.asarray([float(hsd["base_model.encoder.layers.2.attention.q_proj.weight"][0, 0]), float(y[1][100])], np.float64)
+        print(f"hidden_layers {tag}: T={hs[1].shape[1]} H={hs[1].shape[2]} rms L1 {rms(hs[1]):.4f} L2 {rms(hs[2]):.4f}")
+    rec["meta"] = json.dumps(dict(N=N, frame_start=fs, mask_size=ms, seed=seed))
+    np.savez_compressed(os.path.join(out_dir, "hidden_layers.npz"), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
@@ -367,10 +437,14 @@ def main():
                                        VocoderArch.tiny(), 2, 6400, [3, 9], 5, 500, a.out, tmp, legacy_pos=True),
         "tiny_blind": lambda: run_case("tiny_blind", HubertArch.tiny(), VocoderArch.tiny(), 2, 8000, [0, 0], 0, 100, a.out, tmp,
                                        blind=True),
+        # the bench's encoder shape with decisions that discriminate: 4 clips, different mask positions, a centred head
+        "base_b4": lambda: run_case("base_b4", HubertArch.base(), VocoderArch.v1(), 4, 64000, [30, 77, 121, 168], 10, 100, a.out, tmp,
+                                    store_wave="windows", centre_head=True),
         "extend_mel": lambda: extend_cases(a.out),
         "loss_metrics": lambda: loss_cases(a.out, tmp),
         "padded": lambda: padded_cases(a.out),
         "f0_vqvae": lambda: f0_vqvae_cases(a.out),
+        "hidden_layers": lambda: hidden_layer_cases(a.out),
     }
     for k, fn in cases.items():
         if a.only and k not in a.only.split(","):

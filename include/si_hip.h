@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SI_ABI_VERSION 1
+#define SI_ABI_VERSION 2
 
 enum {
     SI_OK = 0,
@@ -87,7 +87,7 @@ typedef struct si_model_desc {
     float   layer_norm_eps;
     int32_t codebook_dim;           /* final_layers Linear(H -> codebook_dim), 80 */
     int32_t num_clusters;           /* K centroids, 100 or 500 */
-    /* vocoder (ResBlock1 generators) */
+    /* vocoder */
     int32_t num_mels;
     int32_t num_ups;
     int32_t up_rates[SI_MAX_UPS], up_kernels[SI_MAX_UPS];
@@ -100,6 +100,9 @@ typedef struct si_model_desc {
     int32_t encoder_math;           /* SI_MATH_* for the encoder GEMMs/convs (attention + head stay fp32) */
     int32_t vocoder_math;           /* SI_MATH_* for the generator convs */
     int32_t vocoder_chunk;          /* clips per vocoder pass (0 = library default; sized to the Infinity Cache) */
+    int32_t resblock_type;          /* 1 (or 0): ResBlock1 -- num_dil (conv_dilated, conv) pairs per block (config_v1 / v2, I_da);
+                                       2: ResBlock2 -- num_dil single dilated convs per block, x = x + conv(lrelu(x))
+                                       (I_ea/hifi_gan/models.py:52-73, selected at :89 by config_v3.json:2) */
 } si_model_desc;
 
 int si_version(void);
@@ -114,7 +117,8 @@ const char* si_last_error(const si_ctx* ctx);
 /* Load a checkpoint.  `host_blob` (host memory) holds fp32 tensors; `index` is text, one tensor per line:
  *     <name> <byte_offset> <ndim> <d0> ... <d(ndim-1)>
  * Names are the reference's state-dict keys: "base_model.<hf key>", "final_layers.{0,1}.{weight,bias}",
- * "generator.<Generator key>" (folded ".weight" or weight-norm ".weight_g"/".weight_v"), "codebook" (K, D).
+ * "generator.<Generator key>" (folded ".weight" or weight-norm ".weight_g"/".weight_v"; ResBlock1 blocks hold
+ * "convs1.<n>" / "convs2.<n>", ResBlock2 blocks "convs.<n>"), "codebook" (K, D).
  * Weight-norm is folded here (dim 0 for the generator, dim 2 for the positional conv, in either the
  * "parametrizations.weight.original{0,1}" or the legacy "weight_g/weight_v" spelling).  The tensors are
  * re-laid-out for the kernels into one packed device blob owned by the context. */

@@ -550,7 +550,7 @@ def get_padding(kernel_size: int, dilation: int = 1) -> int:
 
 
 def generator_forward(sd, arch, mel: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
-    """B1..B4.  Generator.forward with ResBlock1 (I_ea/hifi_gan/models.py:107-123,36-43).
+    """B1..B4.  Generator.forward with ResBlock1 or ResBlock2 blocks (I_ea/hifi_gan/models.py:107-123,36-43,63-68).
     mel (B, 80, Tm') -> (B, 1, Tm'*hop) in (-1, 1).  Accepts folded or weight-normed state dicts (B5)."""
     x = F.conv1d(mel.float(), _conv_weight(sd, "conv_pre"), sd["conv_pre.bias"].float(), padding=3)
     nk = len(arch.resblock_kernel_sizes)
@@ -563,6 +563,13 @@ def generator_forward(sd, arch, mel: torch.Tensor, taps: Optional[dict] = None) 
         for j, (rk, dil) in enumerate(zip(arch.resblock_kernel_sizes, arch.resblock_dilation_sizes)):
             r = f"resblocks.{i * nk + j}."
             y = x
+            if str(getattr(arch, "resblock", "1")) == "2":      # ResBlock2.forward (models.py:63-68): x = x + c(lrelu(x))
+                for n, d in enumerate(dil):
+                    t = F.conv1d(F.leaky_relu(y, LRELU_SLOPE), _conv_weight(sd, f"{r}convs.{n}"), sd[f"{r}convs.{n}.bias"].float(),
+                                 dilation=d, padding=get_padding(rk, d))
+                    y = t + y
+                xs = y if xs is None else xs + y
+                continue
             for n, d in enumerate(dil):
                 t = F.leaky_relu(y, LRELU_SLOPE)
                 t = F.conv1d(t, _conv_weight(sd, f"{r}convs1.{n}"), sd[f"{r}convs1.{n}.bias"].float(),

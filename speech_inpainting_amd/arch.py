@@ -134,10 +134,15 @@ class VocoderArch:
         return cls(upsample_initial_channel=256)
 
     @classmethod
+    def v3(cls) -> "VocoderArch":
+        """I_ea/hifi_gan/config_v3.json: ResBlock2 blocks (one dilated conv per dilation), three upsamplers."""
+        return cls(resblock="2", upsample_rates=(8, 8, 4), upsample_kernel_sizes=(16, 16, 8), upsample_initial_channel=256,
+                   resblock_kernel_sizes=(3, 5, 7), resblock_dilation_sizes=((1, 2), (2, 6), (3, 12)))
+
+    @classmethod
     def from_config(cls, h: dict) -> "VocoderArch":
-        if str(h.get("resblock", "1")) != "1":
-            raise ValueError("only ResBlock1 generators (config_v1/v2) are implemented; "
-                             "config_v3 (ResBlock2) is not on the I_ea predict path (predict.yaml:35)")
+        if str(h.get("resblock", "1")) not in ("1", "2"):
+            raise ValueError(f"resblock={h.get('resblock')!r}: the reference knows '1' and '2' (I_ea/hifi_gan/models.py:89)")
         return cls(resblock=str(h.get("resblock", "1")),
                    upsample_rates=tuple(h["upsample_rates"]),
                    upsample_kernel_sizes=tuple(h["upsample_kernel_sizes"]),

@@ -225,7 +225,7 @@ int plan_layout(si_ctx* ctx) {
             ResW r;
             for (int n = 0; n < d.num_dil; ++n) {
                 r.c1[n] = P.gemm(vm, 1, d.rb_kernels[j], c, c, true);
-                r.c2[n] = P.gemm(vm, 1, d.rb_kernels[j], c, c, true);
+                if (d.resblock_type != 2) r.c2[n] = P.gemm(vm, 1, d.rb_kernels[j], c, c, true);   // ResBlock2 has one conv per dilation
             }
             L.rbs.push_back(r);
         }
@@ -265,6 +265,7 @@ int check_desc(si_ctx* ctx, const si_model_desc* d) {
     if (c % 4) return si_fail(ctx, SI_EINVAL, "final generator width %d must be a multiple of 4", c);
     for (int j = 0; j < d->num_rb; ++j)
         if (d->rb_kernels[j] % 2 == 0) return si_fail(ctx, SI_EINVAL, "resblock kernel %d must be odd", d->rb_kernels[j]);
+    if (d->resblock_type < 0 || d->resblock_type > 2) return si_fail(ctx, SI_EINVAL, "resblock_type %d: 1 (ResBlock1) or 2 (ResBlock2)", d->resblock_type);
     for (int m : {d->encoder_math, d->vocoder_math})
         if (m < SI_MATH_F32 || m > SI_MATH_F16) return si_fail(ctx, SI_EINVAL, "unknown math mode %d", m);
     return SI_OK;
@@ -483,6 +484,12 @@ int pack_weights(si_ctx* ctx, Packer& P) {
             const ResW& R = L.rbs[(size_t)i * d.num_rb + j];
             const std::string rp = G + "resblocks." + std::to_string(i * d.num_rb + j) + ".";
             for (int n = 0; n < d.num_dil; ++n) {
+                if (d.resblock_type == 2) {                       // ResBlock2: `convs.<n>` (I_ea/hifi_gan/models.py:56-61)
+                    const std::string a = rp + "convs." + std::to_string(n);
+                    if (P.folded(a, {c, c, d.rb_kernels[j]}, 0, w)) P.conv(R.c1[n], w, c, c, d.rb_kernels[j]);
+                    P.bias(R.c1[n], a + ".bias", c);
+                    continue;
+                }
                 const std::string a = rp + "convs1." + std::to_string(n), bb = rp + "convs2." + std::to_string(n);
                 if (P.folded(a, {c, c, d.rb_kernels[j]}, 0, w)) P.conv(R.c1[n], w, c, c, d.rb_kernels[j]);
                 P.bias(R.c1[n], a + ".bias", c);
@@ -1116,6 +1123,32 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                 const int rk = d.rb_kernels[j];
                 const float* y = U;
                 const unsigned short* y16 = U16;
+                if (d.resblock_type == 2) {
+                    // ResBlock2 (I_ea/hifi_gan/models.py:63-68): per dilation x = x + conv_d(lrelu(x)) -- ONE convolution with the
+                    // residual (and, on the block's last one, the 1 / num_kernels scale and the MRF accumulate) in its epilogue
+                    for (int n = 0; n < d.num_dil; ++n) {
+                        const int dl = d.rb_dilations[j][n];
+                        const bool last = (n == d.num_dil - 1);
+                        float* ynext = last ? xs : buf[4 + (n & 1)];
+                        unsigned short* ynext16 = last ? xs16 : h16[4 + (n & 1)];
+                        TapGemmParams q = gemm_params(ctx, R.c1[n]);
+                        q.x = y; q.out = ynext; q.res = y;
+                        if (opr) {
+                            q.x = nullptr; q.x16 = y16;
+                            if (r16) { q.res = nullptr; q.res16 = y16; q.out = nullptr; }
+                            const bool want16 = r16 || !last || (j == nk - 1 && i + 1 < d.num_ups);
+                            if (want16) { q.out16 = ynext16; q.out16_slope = r16 ? 1.f : 0.1f; }
+                        }
+                        q.pro_slope = (opr && !r16) ? 1.f : 0.1f;          // operand-ready inputs are already activated
+                        q.nseg = Bc; q.Lin = (int)Lo; q.M = (int)Lo; q.ldx = cout; q.x_seg_stride = Lo * cout;
+                        q.dil = dl; q.pad = dl * (rk - 1) / 2; q.ldo = cout; q.o_seg_stride = Lo * cout; q.olimit = q.o_seg_stride;
+                        if (last) { q.alpha = 1.0f / nk; q.accumulate = (j > 0); q.acc16 = (r16 && j > 0); }
+                        if ((rc = si_launch_tapgemm(ctx, R.c1[n].math, q, st))) return rc;
+                        y = ynext;
+                        y16 = ynext16;
+                    }
+                    continue;
+                }
                 if (r16 && (fuse_mask & cout) && ctx->opt_voc_chain && d.num_dil == 3) {
                     // full-rate stage: the whole resblock (three pairs) as one kernel, residual stream in LDS (reschain.hip)
                     ResChainParams cp{};

@@ -78,7 +78,7 @@ class ModelDesc(C.Structure):
         ("up_rates", C.c_int32 * SI_MAX_UPS), ("up_kernels", C.c_int32 * SI_MAX_UPS), ("up_initial_channel", C.c_int32),
         ("num_rb", C.c_int32), ("rb_kernels", C.c_int32 * SI_MAX_RB), ("num_dil", C.c_int32),
         ("rb_dilations", (C.c_int32 * SI_MAX_DIL) * SI_MAX_RB),
-        ("encoder_math", C.c_int32), ("vocoder_math", C.c_int32), ("vocoder_chunk", C.c_int32),
+        ("encoder_math", C.c_int32), ("vocoder_math", C.c_int32), ("vocoder_chunk", C.c_int32), ("resblock_type", C.c_int32),
     ]
 
 
@@ -122,6 +122,9 @@ def make_desc(harch: HubertArch, varch: VocoderArch, num_clusters: int, encoder_
             d.rb_dilations[j][k] = varch.resblock_dilation_sizes[j][k]
     d.encoder_math, d.vocoder_math = SI_MATH[encoder_math], SI_MATH[vocoder_math]
     d.vocoder_chunk = int(vocoder_chunk)
+    if str(varch.resblock) not in ("1", "2"):
+        raise ValueError(f"resblock={varch.resblock!r}: '1' or '2' (I_ea/hifi_gan/models.py:89)")
+    d.resblock_type = int(varch.resblock)
     return d
 
 

@@ -140,6 +140,10 @@ def synth_generator_state(arch: VocoderArch, seed: int = DEFAULT_SEED + 1, folde
     for i in range(len(arch.upsample_rates)):
         ch = C0 // (2 ** (i + 1))
         for j, (k, dil) in enumerate(zip(arch.resblock_kernel_sizes, arch.resblock_dilation_sizes)):
+            if str(arch.resblock) == "2":                    # ResBlock2: `convs.<n>` only (I_ea/hifi_gan/models.py:56-61)
+                for n in range(len(dil)):
+                    put(f"resblocks.{i * nk + j}.convs.{n}", (ch, ch, k), ch * k, 1.0, ch)
+                continue
             for n in range(len(dil)):
                 put(f"resblocks.{i * nk + j}.convs1.{n}", (ch, ch, k), ch * k, 1.4, ch)
             for n in range(len(dil)):

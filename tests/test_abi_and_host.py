@@ -30,12 +30,12 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/si_hip.h but not exported"
     assert set(names) == set(native.EXPORTS), (set(names) ^ set(native.EXPORTS))
-    assert lib.si_version() == 1
+    assert lib.si_version() == 2
 
 
 def test_desc_struct_matches_header_size():
     # si_create rejects a mismatching struct_size; here only the Python mirror's arithmetic is checked
-    n_i32 = 1 + 4 + 1 + 3 * 8 + 3 + 2 + 1 + 1 + 2 + 2 + 2 * 8 + 1 + 1 + 4 + 1 + 16 + 3
+    n_i32 = 1 + 4 + 1 + 3 * 8 + 3 + 2 + 1 + 1 + 2 + 2 + 2 * 8 + 1 + 1 + 4 + 1 + 16 + 4
     assert ctypes.sizeof(native.ModelDesc) == 4 * n_i32
     d = native.make_desc(HubertArch.large(), VocoderArch.v1(), 500, "bf16", "bf16x3", 4)
     assert d.hidden_size == 1024 and d.feat_norm_layer == 1 and d.stable_layer_norm == 1 and d.conv_bias == 1

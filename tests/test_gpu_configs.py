@@ -301,3 +301,61 @@ def test_f0_vqvae_front_matches_reference_goldens():
         d = ((x[:, None, :] - k[None]) ** 2).sum(-1)
         dz, dr = d.gather(1, codes.reshape(-1, 1)), d.gather(1, want.reshape(-1, 1))
         assert bool(((dz - dr).abs() <= 1e-4 * dr.abs() + 1e-6).all()) and agree >= 0.98
+
+
+@pytest.mark.gpu
+def test_local_huggingface_directory_loads_and_encodes_like_the_pt_route(tmp_path):
+    """The "HuggingFace checkpoint loader": a LOCAL directory (config.json + model.safetensors, `hubert.`-prefixed keys as in a
+    HubertForCTC file) supplies the architecture and the encoder weights in place of `from_pretrained(name)` (I_ea/model.py:26-40);
+    with the head taken from the CustomModel .pt it must encode exactly like the .pt route (I_ea/predict.py:149)."""
+    import json
+    from safetensors.torch import save_file
+    from speech_inpainting_amd import checkpoint, synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import InpaintingEngine
+    harch, varch = HubertArch.tiny(), VocoderArch.tiny()
+    hsd, gsd, cb = synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook(100)
+    d = tmp_path / "hubert-tiny"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(harch.to_hf()))
+    save_file({"hubert." + k[len("base_model."):]: v.contiguous() for k, v in hsd.items() if k.startswith("base_model.")}, str(d / "model.safetensors"))
+    torch.save(hsd, tmp_path / "save_checkpoint.pt")
+    sd_dir, arch_dir = checkpoint.load_hubert_checkpoint(str(d))
+    sd_pt, _ = checkpoint.load_hubert_checkpoint(str(tmp_path / "save_checkpoint.pt"), "base")
+    assert arch_dir == harch and not any(k.startswith("final_layers") for k in sd_dir)
+    sd_dir.update({k: v for k, v in sd_pt.items() if k.startswith("final_layers.")})
+    wave = synth.synth_wave(2, 8000, 5).cuda()
+    a = InpaintingEngine(arch_dir, varch, 100, "cuda:0", "bf16", "fp16").load_state(sd_dir, gsd, cb).encode(wave)
+    b = InpaintingEngine(harch, varch, 100, "cuda:0", "bf16", "fp16").load_state(sd_pt, gsd, cb).encode(wave)
+    assert torch.equal(a, b)
+    # the directory alone (no trained head): the engine initialises final_layers as the reference's constructor does
+    c = InpaintingEngine(arch_dir, varch, 100, "cuda:0").load_state(checkpoint.load_hubert_checkpoint(str(d))[0], gsd, cb).encode(wave)
+    assert c.shape == a.shape and bool(torch.isfinite(c).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("voc,tol", [("fp32", 1e-6), ("bf16x3", 1e-5), ("fp16", 2e-4), ("bf16", 1e-3)])
+def test_resblock2_generator_matches_reference_golden(voc, tol):
+    """config_v3.json generators (`resblock: "2"`, I_ea/hifi_gan/models.py:52-73): one dilated conv per dilation with the residual, the
+    1 / num_kernels scale and the MRF accumulate in its epilogue -- against the output of the reference's own `Generator(h)`
+    (tests/golden/gen_v3.npz) in every arithmetic mode."""
+    import os
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import Generator, InpaintingEngine
+    from tests.common import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "gen_v3.npz"))
+    harch, varch = HubertArch.tiny(), VocoderArch.v3()
+    gsd = synth.synth_generator_state(varch, synth.DEFAULT_SEED + 1)
+    mel = synth.synth_mel(2, 40, 80, synth.DEFAULT_SEED + 4)
+    eng = InpaintingEngine(harch, varch, 100, "cuda:0", "fp32", voc).load_state(synth.synth_hubert_state(harch), gsd, synth.synth_codebook(100))
+    wav = Generator(eng)(mel.cuda())[:, 0, :].cpu()
+    ref = torch.from_numpy(z["wave"])
+    err = rms(wav, ref)
+    print(f"ResBlock2 generator, vocoder {voc}: waveform rms error {err:.3e} (signal rms {float(z['wave_rms']):.3f})")
+    assert wav.shape == ref.shape and err <= tol
+    # folded weights (after remove_weight_norm) load to the same result
+    if voc == "fp32":
+        eng2 = InpaintingEngine(harch, varch, 100, "cuda:0").load_state(synth.synth_hubert_state(harch), synth.synth_generator_state(varch, synth.DEFAULT_SEED + 1, folded=True),
+                                                                       synth.synth_codebook(100))
+        assert rms(Generator(eng2)(mel.cuda())[:, 0, :].cpu(), ref) <= tol

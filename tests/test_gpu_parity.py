@@ -22,7 +22,7 @@ def _run(eng, c):
     return {k: v.cpu() for k, v in out.items()}
 
 
-@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "tiny_blind", "base_4s", "large_4s"])
+@pytest.mark.parametrize("name", ["tiny_group", "tiny_layer", "tiny_blind", "base_4s", "large_4s", "base_b4"])
 def test_fp32_matches_reference_goldens(name):
     """fp32 mode vs outputs of the reference's own modules: labels bit-exact, waveform RMS <= 1e-3 (north-star gate)."""
     c = load_case(name)
@@ -37,6 +37,8 @@ def test_fp32_matches_reference_goldens(name):
         err = rms(out["wave"], z["wave"])
     else:
         err = max(rms(out["wave"][:, :2048], z["wave_head"]), rms(out["wave"][:, -2048:], z["wave_tail"]))
+    if "wave_win" in z.files:         # base_b4: the samples each clip's spliced frames reach
+        err = max([err] + [rms(out["wave"][i, lo:lo + 16384], z["wave_win"][i]) for i, lo in enumerate(z["wave_win_lo"])])
     print(f"{name}: waveform rms error {err:.3e} (signal rms {float(z['wave_rms']):.3f})")
     assert err <= 1e-3
     assert err <= 1e-4            # what exact-fp32 MFMA actually delivers; keeps regressions visible
@@ -139,6 +141,46 @@ def test_bf16_encoder_mode_label_agreement_and_waveform(name):
     assert rel <= BF16_FEAT_REL[name]
     agree, _ = _check_wave(name + " bf16/fp32", c, out, 1e-3)
     assert agree >= BF16_AGREE_FLOOR[name]
+
+
+def test_bf16_labels_flip_only_where_the_fp32_margin_is_inside_the_feature_error():
+    """The base-size fixture with DISCRIMINATING labels (base_b4: 4 clips, different mask positions, a head centred on the masked
+    frames -> 8 distinct codewords over 40 frames, several inside one clip) under the bench's encoder arithmetic.  With a centred
+    head the decisions hang on the frame-to-frame deviations of a randomly initialised encoder (2 % of the feature norm), the
+    same size as bf16's feature error, so some labels flip -- as they must.  What is asserted: (1) every flipped label is a
+    near-tie for the REFERENCE's own cosines: its fp32 margin is no larger than twice the distance between the unit vectors of
+    the bf16 and the reference feature (no cosine can move further than that); (2) the agreement stays above the measured
+    floor; (3) the waveform meets the gate wherever the agreeing labels reach, and equals the oracle's vocoder on the mel this
+    run spliced everywhere else."""
+    import torch.nn.functional as F
+    from oracle import ref_cpu as R
+    c = load_case("base_b4")
+    z, m = c["z"], c["meta"]
+    out = _run(_engine(c, enc="bf16", voc="fp16"), c)
+    ref_f = torch.from_numpy(z["feats"])
+    lm = m["lm"]
+    v_ref = torch.stack([ref_f[b, p:p + lm] for b, p in enumerate(c["frame_pos"])]).reshape(-1, 80)
+    v_got = torch.stack([out["feats"][b, p:p + lm] for b, p in enumerate(c["frame_pos"])]).reshape(-1, 80)
+    _, cc = R.codebook_tables(c["cb"])
+    sim = F.cosine_similarity(v_ref[:, None, :], cc[None], dim=-1)                   # the reference's own cosines
+    want, got = torch.from_numpy(z["labels"]).reshape(-1), out["labels"].reshape(-1)
+    du = (F.normalize(v_ref, dim=1) - F.normalize(v_got, dim=1)).norm(dim=1)         # how far each unit feature moved
+    flipped = (want != got).nonzero().reshape(-1).tolist()
+    agree = 1.0 - len(flipped) / want.numel()
+    print(f"base_b4 bf16 encoder: agreement {agree:.3f} ({len(flipped)} of {want.numel()} flipped), unit-feature shift median {float(du.median()):.3e} "
+          f"max {float(du.max()):.3e}, distinct reference labels {len(set(want.tolist()))}")
+    for i in flipped:
+        margin = float(sim[i, want[i]] - sim[i, got[i]])
+        print(f"    frame {i}: reference label {int(want[i])} -> {int(got[i])}, fp32 margin {margin:.3e}, bound {2 * float(du[i]):.3e}")
+        assert 0.0 <= margin <= 2.0 * float(du[i]) + 1e-6
+    assert agree >= 0.6
+    assert bool(torch.isfinite(out["wave"]).all())
+    # the waveform: the oracle's vocoder on the mel THIS run spliced (flipped codewords legitimately change what they reach)
+    ref2 = R.generator_forward(c["gsd"], c["varch"], R.extend_mel(out["mel"]))[:, 0, :]
+    err2 = rms(out["wave"], ref2)
+    head = max(rms(out["wave"][:, :2048], z["wave_head"]), rms(out["wave"][:, -2048:], z["wave_tail"]))
+    print(f"base_b4 headline arithmetic: waveform vs the oracle's vocoder on this run's mel {err2:.3e}; head / tail vs the reference {head:.3e}")
+    assert err2 <= 1e-3 and head <= 1e-3
 
 
 @pytest.mark.parametrize("name", ["base_4s", "large_4s", "tiny_group"])

@@ -128,3 +128,33 @@ def test_lingemm_matches_tapgemm_in_the_bf16_encoder(arch):
     print(f"{arch}: lingemm vs tapgemm {d:.3e} relative; vs the fp32 encoder: lingemm {e1:.3e}, tapgemm {e0:.3e}")
     assert bool(torch.isfinite(outs["1"]).all())
     assert d <= 1.2e-2 and e1 <= 2e-2 and e0 <= 2e-2
+
+
+@pytest.mark.parametrize("scale", [0.125, 1.0, 8.0])
+def test_fp16_vocoder_across_activation_scales(scale):
+    """The fp16 activation stream at other operating points than the synthetic checkpoint's: `conv_pre` scaled by 1/8 and 8 (the
+    stack is positively homogeneous up to the later layers' biases, so every activation in front of the tanh scales with it:
+    1/8 puts the stream where the biases dominate, 8 drives the final tanh into saturation on peaks).  fp16 keeps a RELATIVE
+    precision, so the waveform error must stay a fixed fraction of the signal: <= 1e-2 of the signal RMS against the fp32
+    oracle (measured 1e-3 at scale 1), and inside the 1e-3 absolute gate at scale 1."""
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import VocoderArch
+    varch = VocoderArch.v1()
+    gsd = synth.synth_generator_state(varch)
+    gsd["conv_pre.weight_g"] = gsd["conv_pre.weight_g"] * scale           # w = g v / |v|: scales the folded weight
+    gsd["conv_pre.bias"] = gsd["conv_pre.bias"] * scale
+    mel = synth.synth_mel(2, 40, 80, 91)
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = R.generator_forward(gsd, varch, mel)[:, 0, :]
+    got = _engine(varch, gsd, True).vocode(mel.cuda(), stretch=False).cpu()
+    x3 = _engine(varch, gsd, True, voc="bf16x3").vocode(mel.cuda(), stretch=False).cpu()
+    sig, err, err3 = rms(ref), rms(got, ref), rms(x3, ref)
+    print(f"conv_pre x{scale}: signal rms {sig:.4f} absmax {float(ref.abs().max()):.3f}; fp16 stream error {err:.3e} = {err / sig:.2e} of signal; "
+          f"bf16x3 (fp32-equivalent) {err3:.3e}")
+    assert bool(torch.isfinite(got).all())
+    assert err <= 1e-2 * sig
+    assert err3 <= 1e-4 * max(sig, 0.1)
+    if scale == 1.0:
+        assert err <= 1e-3

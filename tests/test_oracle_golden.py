@@ -156,6 +156,31 @@ def test_f0_vqvae_restatement_matches_the_reference_modules():
         assert len(set(z[f"codes_{T}"].reshape(-1).tolist())) >= 4               # the fixture exercises several bins
 
 
+def test_resblock2_generator_matches_reference():
+    """`Generator(h)` with `resblock: "2"` in the config_v3.json shape (I_ea/hifi_gan/models.py:52-73,89): the oracle against the
+    reference's own module output (tests/golden/gen_v3.npz)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import VocoderArch
+    from tests.common import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "gen_v3.npz"))
+    varch = VocoderArch.v3()
+    assert VocoderArch.from_config(dict(resblock="2", upsample_rates=[8, 8, 4], upsample_kernel_sizes=[16, 16, 8], upsample_initial_channel=256,
+                                        resblock_kernel_sizes=[3, 5, 7], resblock_dilation_sizes=[[1, 2], [2, 6], [3, 12]])) == varch
+    gsd = synth.synth_generator_state(varch, synth.DEFAULT_SEED + 1)
+    mel = synth.synth_mel(2, 40, 80, synth.DEFAULT_SEED + 4)
+    assert np.allclose([float(gsd["resblocks.0.convs.1.weight_v"][0, 0, 0]), float(mel[0, 0, 0])], z["probe"], atol=1e-7)
+    assert not any("convs1" in k or "convs2" in k for k in gsd) and len(gsd) == 69
+    with torch.no_grad():
+        w = R.generator_forward(gsd, varch, mel)[:, 0, :]
+    ref = torch.from_numpy(z["wave"])
+    assert w.shape == ref.shape == (2, 40 * 256)
+    assert float((w - ref).pow(2).mean().sqrt()) <= 1e-6
+
+
 def test_hidden_state_restatement_matches_transformers_hidden_states():
     """Row f-2: the oracle's `hubert_get_feats` (fairseq `extract_features(output_layer=L)` restated; fairseq is absent) against
     `transformers.HubertModel(output_hidden_states=True).hidden_states[L]` on inputs prepared by the reference's own

@@ -373,6 +373,23 @@ def f0_vqvae_cases(out_dir):
     np.savez_compressed(os.path.join(out_dir, "f0_vqvae.npz"), **rec)
 
 
+def generator_v3_case(out_dir):
+    """The reference's `Generator(h)` with ResBlock2 blocks (I_ea/hifi_gan/models.py:52-73, selected at :89 by `resblock: "2"`)
+    in the config_v3.json shape: ups (8, 8, 4), C0 = 256, kernels (3, 5, 7), dilations [[1, 2], [2, 6], [3, 12]].  Weight-norm state
+    dict -> load_state_dict -> remove_weight_norm -> forward, as predict.py:117-123 does for V1."""
+    varch = VocoderArch.v3()
+    gsd = synth.synth_generator_state(varch, synth.DEFAULT_SEED + 1)
+    gen = build_reference_generator(varch, gsd)
+    mel = synth.synth_mel(2, 40, 80, synth.DEFAULT_SEED + 4)
+    with torch.no_grad():
+        wav = gen(mel)[:, 0, :]
+    rec = dict(wave=wav.numpy(), wave_rms=np.float64(rms(wav)),
+               probe=np.asarray([float(gsd["resblocks.0.convs.1.weight_v"][0, 0, 0]), float(mel[0, 0, 0])], np.float64),
+               meta=json.dumps(dict(varch=varch.__dict__, seed=synth.DEFAULT_SEED, B=2, Tm=40), default=list))
+    np.savez_compressed(os.path.join(out_dir, "gen_v3.npz"), **rec)
+    print(f"gen_v3: wave {tuple(wav.shape)} rms {rms(wav):.4f} absmax {float(wav.abs().max()):.3f}; state keys {len(gsd)}")
+
+
 def hidden_layer_cases(out_dir):
     """I_da's encoder call (`HubertFeatureReader.get_feats`, I_da/src/hubert_feature_reader.py:44-67) needs fairseq, which is not
     in this image.  The statements around the model ARE the reference's: `(y + 1e-6) * mask` on the float64 clip
@@ -445,6 +462,7 @@ def main():
         "padded": lambda: padded_cases(a.out),
         "f0_vqvae": lambda: f0_vqvae_cases(a.out),
         "hidden_layers": lambda: hidden_layer_cases(a.out),
+        "gen_v3": lambda: generator_v3_case(a.out),
     }
     for k, fn in cases.items():
         if a.only and k not in a.only.split(","):

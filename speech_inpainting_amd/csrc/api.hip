@@ -80,6 +80,7 @@ struct si_ctx {
     std::map<const void*, size_t> dyn_lds;   // per kernel: dynamic-LDS limit already raised on this context's device
     // arithmetic-path options, read from the environment when the context is created (all default to 1)
     bool opt_voc_opready = true, opt_voc_res16 = true, opt_enc_opready = true, opt_att_bf16 = true, opt_enc_lingemm = true;
+    int opt_gemm256 = 1;                     // encoder GEMMs on 256 x 256 tiles: 0 never, 1 by the shape rule, 2 whenever the shape allows (tests)
     int opt_voc_chain = 1;                   // whole-resblock kernel on the C = 32 stage (SI_VOC_CHAIN=0: one launch per conv pair)
     int opt_voc_fuse = 1;                    // 0: never, 1: every covered width, otherwise a mask of the channel counts to fuse (32 | 64 | 128 | 256)
     // constant tables of the mel front-end (built on first use): DFT matrix [Npad][n_fft] = rows cos | -sin, periodic
@@ -127,6 +128,13 @@ void si_prof_begin(si_ctx* ctx, const char* name, double flops, double bytes, hi
     ctx->prof_open = (int)ctx->prof_recs.size();
     ctx->prof_recs.push_back(r);
 }
+const char* si_prof_shape_name(const char* name, long M, int N, int K) {
+    static const bool on = getenv("SI_PROF_SHAPES") && atoi(getenv("SI_PROF_SHAPES")) != 0;
+    if (!on) return name;
+    static thread_local char buf[48];
+    snprintf(buf, sizeof(buf), "%s_%ldx%dx%d", name, M, N, K);
+    return buf;
+}
 int si_ensure_dyn_lds(si_ctx* ctx, const void* kern, size_t bytes) {
     if (bytes <= 64 * 1024) return SI_OK;
     size_t& have = ctx->dyn_lds[kern];
@@ -136,6 +144,7 @@ int si_ensure_dyn_lds(si_ctx* ctx, const void* kern, size_t bytes) {
     }
     return SI_OK;
 }
+int si_opt_gemm256(const si_ctx* ctx) { return ctx->opt_gemm256; }
 int si_num_cus(si_ctx* ctx) {
     if (ctx->num_cus <= 0) {
         int n = 0;
@@ -614,6 +623,7 @@ int si_create(si_ctx** out, int device_id, const si_model_desc* desc) {
     ctx->opt_enc_opready = env_flag("SI_ENC_OPREADY");
     ctx->opt_att_bf16 = env_flag("SI_ATT_BF16");
     ctx->opt_enc_lingemm = env_flag("SI_ENC_LINGEMM");
+    ctx->opt_gemm256 = getenv("SI_ENC_GEMM256") ? atoi(getenv("SI_ENC_GEMM256")) : 1;
     plan_layout(ctx);
     *out = ctx;
     return SI_OK;

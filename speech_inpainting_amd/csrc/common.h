@@ -16,6 +16,9 @@ int si_fail(si_ctx* ctx, int code, const char* fmt, ...);
 // HIP-event bracket around one kernel launch (no-op unless si_profile_start armed the context)
 void si_prof_begin(si_ctx* ctx, const char* name, double flops, double bytes, hipStream_t st);
 void si_prof_end(si_ctx* ctx, hipStream_t st);
+// Diagnostic (SI_PROF_SHAPES=1 in the environment): the family name with the GEMM shape appended, so that a per-kernel table
+// separates the launches of one instantiation; otherwise `name` itself.  The returned pointer is valid until the next call.
+const char* si_prof_shape_name(const char* name, long M, int N, int K);
 // Raise a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) when a launch needs more than the
 // 64 KB default.  The high-water mark is kept per context (= per device): a process-wide cache would skip the call
 // for a second context on another GPU.
@@ -84,8 +87,12 @@ struct LinGemmParams {
     int ldo; long o_seg_stride;
     int act;
     int xcd_rows;                               // set by the launcher: > 0 = XCD-aware tile order over this many row blocks
+    int persistent;                             // set by the launcher (gemm256): workgroups walk tiles slot, slot + grid / 8, ... of their XCD's list
 };
 int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st);
+// The same contract on 256 x 256 tiles with LDS-DMA staging (gemm256.hip), for the shapes whose tiles fill the chip; returns 1 otherwise.
+int si_launch_gemm256(si_ctx* ctx, const LinGemmParams& p, hipStream_t st);
+int si_opt_gemm256(const si_ctx* ctx);      // SI_ENC_GEMM256: 0 never, 1 by the shape rule (default), 2 whenever the shape allows
 
 // ------------------------------------------------------------------------------------------------
 // encoder kernels (encoder_kernels.hip)

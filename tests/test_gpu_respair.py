@@ -130,6 +130,45 @@ def test_lingemm_matches_tapgemm_in_the_bf16_encoder(arch):
     assert d <= 1.2e-2 and e1 <= 2e-2 and e0 <= 2e-2
 
 
+@pytest.mark.parametrize("arch,B,N", [("base", 3, 24000), ("large", 2, 16000), ("base", 1, 64000)])
+def test_gemm256_matches_lingemm_in_the_bf16_encoder(arch, B, N):
+    """The 256 x 256-tile GEMM (gemm256.hip: LDS-DMA staging, two wave groups one barrier apart) against the 128-row kernels on
+    the same bf16 operands: SI_ENC_GEMM256=2 sends EVERY shape it covers through it (feature-extractor convolutions with ragged
+    last tiles, both projections, all four Linears of a layer, fp32 + residual and bf16 outputs, GELU epilogues), =0 none.  Same
+    products, fp32 accumulation in another order: the head outputs agree like lingemm and the tap-GEMM do; and both stay
+    inside the bf16 mode's error against the fp32 encoder.  Two runs of the new kernel are bit-identical (no race in the
+    DMA / barrier schedule shows up as run-to-run noise), and a clip does not depend on its batch neighbours."""
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import InpaintingEngine
+    harch = HubertArch.base() if arch == "base" else HubertArch.large()
+    varch = VocoderArch.tiny()
+    hsd, gsd, cb = synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook(50)
+    wave = synth.synth_wave(B, N, 93).cuda()
+    outs, engs = {}, {}
+    for flag in ("2", "0"):
+        os.environ["SI_ENC_GEMM256"] = flag
+        try:
+            eng = InpaintingEngine(harch, varch, 50, "cuda:0", "bf16", "fp32").load_state(hsd, gsd, cb)
+        finally:
+            os.environ.pop("SI_ENC_GEMM256", None)
+        eng.ctx.profile_start(4000)
+        outs[flag] = eng.encode(wave).cpu()
+        names = {e["name"] for e in eng.ctx.profile_stop()}
+        assert any(n.startswith("gemm256_bf16") for n in names) == (flag == "2"), names
+        engs[flag] = eng
+    again = [engs["2"].encode(wave).cpu() for _ in range(3)]
+    assert all(torch.equal(a, outs["2"]) for a in again)
+    if B > 1:
+        assert torch.equal(engs["2"].encode(wave[1:2].contiguous()).cpu(), outs["2"][1:2])
+    ref = InpaintingEngine(harch, varch, 50, "cuda:0", "fp32", "fp32").load_state(hsd, gsd, cb).encode(wave).cpu()
+    d = rms(outs["2"], outs["0"]) / rms(outs["0"])
+    e2, e0 = rms(outs["2"], ref) / rms(ref), rms(outs["0"], ref) / rms(ref)
+    print(f"{arch} B={B} N={N}: gemm256 vs 128-row kernels {d:.3e} relative; vs the fp32 encoder: gemm256 {e2:.3e}, 128-row {e0:.3e}")
+    assert bool(torch.isfinite(outs["2"]).all())
+    assert d <= 1.2e-2 and e2 <= 2e-2 and e0 <= 2e-2
+
+
 @pytest.mark.parametrize("scale", [0.125, 1.0, 8.0])
 def test_fp16_vocoder_across_activation_scales(scale):
     """The fp16 activation stream at other operating points than the synthetic checkpoint's: `conv_pre` scaled by 1/8 and 8 (the

@@ -187,6 +187,23 @@ int si_launch_mel_project(si_ctx* ctx, const float* spec, int ld_spec, int nbin,
 int si_launch_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const float* taps, int ntaps, int up, int down,
                             int pre_remove, int n_out, float* y, hipStream_t st);
 
+// erf-GELU of the bf16 encoder's GEMM epilogues (lingemm.hip, gemm256.hip: the SAME function, their results are bit-identical).
+// erf by Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 -- below one fp32 ulp of the result for |x| >= 1 and far below the bf16
+// rounding every consumer of these outputs applies; 15 VALU operations instead of libm erff's ~31 with two divergent branches.
+__device__ __forceinline__ float si_gelu_fast(float x) {
+    const float z = x * 0.70710678118654752440f;
+    const float az = __builtin_fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);
+    const float erf = __builtin_copysignf(fmaf(-poly, e, 1.0f), z);
+    return 0.5f * x * (1.0f + erf);
+}
+
 // leaky-ReLU(0.1) of an accumulator as max(v, 0.1 v) in two VALU ops: fmaxf() would first canonicalise both operands
 // (a v_max_f32 v, v, v each), which nothing downstream of an MFMA accumulator needs
 __device__ __forceinline__ float si_lrelu01(float v) {

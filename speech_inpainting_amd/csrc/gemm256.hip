@@ -36,6 +36,7 @@
 //   * Epilogue from the accumulators (bias, fast erf-GELU, residual; bf16 through a half trade between lanes l and l + 16).
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -52,22 +53,28 @@ constexpr int G_HALF = 128 * G_ROWB;                                   // one ha
 constexpr int G_PAIR = 2 * G_HALF;                                     // both halves of one operand of one K-tile: 32 KB
 constexpr int G_WBASE = 2 * G_PAIR;                                    // LDS: A ring of 2 pairs at 0, W ring of 3 pairs behind it: 160 KB
 
-// Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7): see lingemm.hip
-__device__ __forceinline__ float g_gelu(float x) {
-    const float z = x * 0.70710678118654752440f;
-    const float az = __builtin_fabsf(z);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);
-    const float erf = __builtin_copysignf(fmaf(-poly, e, 1.0f), z);
-    return 0.5f * x * (1.0f + erf);
-}
-
 #define G_LDS(off) ((__attribute__((address_space(3))) void*)(smem + (off)))
+
+// Diagnostic build only (-DG256_TIMELINE; tools/exp_encoder_only.py): wall-clock totals of every workgroup's wave 0 in 100 MHz
+// ticks, [shape class: 0 = per-clip launches with 24 K-tiles, 1 = N 2304, 2 = N 3072, 3 = other][0 prologue, 1 K loops, 2 epilogues,
+// 3 tiles, 4 workgroups, 5 whole kernel].
+#ifdef G256_TIMELINE
+__device__ unsigned long long g256_tl[4][6];
+#define G_TL_DECL const unsigned long long tl_0 = wall_clock64(); unsigned long long tl_t = tl_0, tl_acc[3] = {0, 0, 0}, tl_tiles = 0;
+#define G_TL(ph) { const unsigned long long n_ = wall_clock64(); tl_acc[ph] += n_ - tl_t; tl_t = n_; }
+#define G_TL_TILE ++tl_tiles;
+#define G_TL_FLUSH if (threadIdx.x == 0) { const int c_ = (p.nseg > 1 && p.K == 1536) ? 0 : (p.N == 2304 ? 1 : (p.N == 3072 ? 2 : 3)); for (int q_ = 0; q_ < 3; ++q_) atomicAdd(&g256_tl[c_][q_], tl_acc[q_]); atomicAdd(&g256_tl[c_][3], tl_tiles); atomicAdd(&g256_tl[c_][4], 1ull); atomicAdd(&g256_tl[c_][5], wall_clock64() - tl_0); }
+extern "C" int si_debug_g256_timeline(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g256_tl), sizeof(g256_tl)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[4][6] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g256_tl), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define G_TL_DECL
+#define G_TL(ph)
+#define G_TL_TILE
+#define G_TL_FLUSH
+#endif
 
 __global__ __launch_bounds__(G_NT, 2) void gemm256_kernel(const LinGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // A [2][half 0 | half 1] then W [3][half 0 | half 1], [128 rows][128 bytes] each
@@ -78,21 +85,24 @@ __global__ __launch_bounds__(G_NT, 2) void gemm256_kernel(const LinGemmParams p)
 
     const int ntn = p.N / G_BN;
     const int mtiles = (p.M + G_BM - 1) / G_BM;
-    // XCD-aware, persistent tile walk.  Workgroup ids b and b + 8 share an L2: all column tiles of one row block go to ONE XCD
-    // (its A rows are fetched into one L2, not eight).  Workgroup b takes slots (b >> 3) + i * (gridDim.x >> 3) of its XCD's
-    // list, slot s = column tile s % ntn of row block xcd + 8 * (s / ntn).  p.xcd_rows = row blocks (all segments); the
-    // launcher makes the grid a multiple of 8 and sets p.persistent = 0 when the workgroup must stop after its first tile.
+    // XCD-aware, persistent tile walk.  Workgroup ids b and b + 8 share an L2 (dealt round-robin over the 8 XCDs).  The tiles, in
+    // row-block-major order (the column tiles of a row block adjacent), are cut into 8 CONTIGUOUS, equally long runs, one per
+    // XCD: a row block's A rows are fetched into one L2 (two at a seam), not eight, and no XCD gets more tiles than another
+    // (with whole row blocks per XCD the 25 row blocks of the flat M = 6368 launches put 36 tiles on XCD 0's 32 CUs: two
+    // rounds).  Workgroup b takes elements (b >> 3) + i * (gridDim.x >> 3) of its XCD's run; p.xcd_rows = number of tiles;
+    // p.persistent = 0: the workgroup stops after its first tile.
     const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slot_step = gridDim.x >> 3;
+    const int run0 = (int)((long)p.xcd_rows * xcd / 8), run1 = (int)((long)p.xcd_rows * (xcd + 1) / 8);
     struct TileRef { int seg, m0, n0; bool valid; };
     auto decode = [&](int it) {
         TileRef r{0, 0, 0, false};
         if (it > 0 && !p.persistent) return r;
-        const int s = slot0 + it * slot_step;
-        const int mtx = xcd + 8 * (s / ntn);
-        if (mtx >= p.xcd_rows) return r;
+        const int tile = run0 + slot0 + it * slot_step;
+        if (tile >= run1) return r;
+        const int mtx = tile / ntn;
         r.seg = mtx / mtiles;
         r.m0 = (mtx - r.seg * mtiles) * G_BM;
-        r.n0 = (s % ntn) * G_BN;
+        r.n0 = (tile - mtx * ntn) * G_BN;
         r.valid = true;
         return r;
     };
@@ -203,6 +213,7 @@ __global__ __launch_bounds__(G_NT, 2) void gemm256_kernel(const LinGemmParams p)
     typedef std::integral_constant<int, 2> I2;
 
     // ---- prologue: K-tiles 0 and 1 of the first tile requested; tile 0 landed and visible
+    G_TL_DECL
     stage_a(0, 0, 0); stage_a(0, 1, 0); stage_w(0, 0, 0); stage_w(0, 1, 0);
     stage_a(1, 0, 1); stage_a(1, 1, 1); stage_w(1, 0, 1); stage_w(1, 1, 1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -212,6 +223,7 @@ __global__ __launch_bounds__(G_NT, 2) void gemm256_kernel(const LinGemmParams p)
 
     const bool gelu = p.act == SI_ACT_GELU;
     const bool has_res = p.res != nullptr;
+    G_TL(0)
     for (int it = 0;; ++it) {
         const TileRef nxt = decode(it + 1);
         has_next = nxt.valid;
@@ -230,6 +242,7 @@ __global__ __launch_bounds__(G_NT, 2) void gemm256_kernel(const LinGemmParams p)
             if (t + 5 < nk) ktile(I1{}, I2{}, t + 5);
         }
 
+        G_TL(1)
         // ---- epilogue from the accumulators: lane (r16, kg) holds row 16 mi + r16, columns 16 nj + 4 kg + [0, 4) of the wave's tile.
         // (Conditions hoisted out of the unrolled loops: a per-element "load or zero" makes hipcc branch around every load and
         // wait vmcnt(0) behind each -- 32 dependent L2 round trips per lane.)  The next tile's first K-tiles are in flight.
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(G_NT, 2) void gemm256_kernel(const LinGemmParams p)
                 f32x4 v = acc[i][j] + bv[j];
                 if (gelu) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = g_gelu(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = si_gelu_fast(v[e]);
                 }
                 if (has_res) v += rv[j];
                 if (p.out && live) *reinterpret_cast<f32x4*>(p.out + orow + 16 * j + 4 * kg) = v;
@@ -280,9 +293,12 @@ __global__ __launch_bounds__(G_NT, 2) void gemm256_kernel(const LinGemmParams p)
                 }
             }
         }
+        G_TL(2)
+        G_TL_TILE
         if (!has_next) break;
         cur = nxt; a_base = a_next; w_base = w_next;
     }
+    G_TL_FLUSH
     if (wr == 0) __builtin_amdgcn_s_barrier();                         // rejoin the groups (equal barrier counts)
 }
 
@@ -292,29 +308,33 @@ int si_launch_gemm256(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     if (p.x_bytes <= 0 || p.w_bytes <= 0 || (long)p.nseg * p.x_seg_stride * 2 + (long)(p.M + 256) * p.lda * 2 >= (1L << 31)) return 1;
     if ((long)(p.N + 256) * p.Cin * 2 + (long)p.ntaps * p.w_tap_stride * 2 >= (1L << 31)) return 1;
     const int mtiles = (p.M + G_BM - 1) / G_BM;
-    // The rule depends on the LAYER's shape only -- never on the batch size -- so that a clip's result does not depend on
-    // how many clips share the launch (each output element is the same sum in the same order whatever tile it falls in, but
-    // the two kernels order the sum differently).  Per-clip launches (nseg > 1: the feature extractor's convolutions): worth
-    // it while the padded rows stay few, M >= 700 of a clip; flat launches (the transformer's Linears over all frames): for
-    // the wide outputs, N >= 2048, which fill the chip's 256 workgroup slots at the benchmark's batch.
+    // The results are bit-identical to lingemm's (same K order, same MFMA and operand roles, same epilogue), so the choice is
+    // purely one of speed and may depend on the batch: 256-row tiles with one workgroup per CU pay when the tiles fill whole
+    // rounds of the chip's CUs and few of their rows are padding.  (B = 32 x 4 s, HuBERT-base: the first four strided
+    // convolutions and the QKV projection; FFN1's 300 tiles are 1.17 rounds and stay on the 128-row kernel.)
     const int opt = si_opt_gemm256(ctx);
     if (opt == 0) return 1;
-    if (opt == 1 && !(p.nseg > 1 ? p.M >= 700 : p.N >= 2048)) return 1;
+    if (opt == 1) {
+        const int cus = si_num_cus(ctx);
+        const long tiles = (long)p.nseg * mtiles * (p.N / G_BN);
+        const double fill = (double)tiles / (double)((tiles + cus - 1) / cus * cus);
+        const double rows = (double)p.M / ((double)mtiles * G_BM);
+        if (fill * rows < 0.72) return 1;
+    }
     const size_t lds = 5 * (size_t)G_PAIR;                             // all 160 KB of a CU's LDS
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm256_kernel), lds)) return rc;
     LinGemmParams q = p;
-    const int rows_total = p.nseg * mtiles;
-    const int ntn = p.N / G_BN;
-    q.xcd_rows = rows_total;
-    // one workgroup per CU walks its tiles and requests the next tile's first K-tiles under the last two of the current one
-    // (its prologue and the epilogue's store burst then overlap another tile's MFMAs: non-persistent, every round of 256 tiles
-    // started and ended together and cost 15 us of memory bursts with idle matrix pipes).  The tiles must start on ring slots
-    // 0 / 0: K a multiple of 6 K-tiles; otherwise one workgroup per tile.
-    const int slots_per_xcd = (rows_total + 7) / 8 * ntn;              // tiles in one XCD's list (the last row blocks may be absent)
+    const int tiles = p.nseg * mtiles * (p.N / G_BN);
+    q.xcd_rows = tiles;
+    // One workgroup per CU; with more tiles than CUs a workgroup walks its XCD's run and requests the next tile's first K-tiles
+    // under the last two of the current one.  Tiles must then start on ring slots 0 / 0: K a multiple of 6 K-tiles; otherwise
+    // one workgroup per tile.
+    const int run_max = (tiles + 7) / 8;                               // longest run of one XCD
     const int nk = p.K / G_BK;
     const int cus = si_num_cus(ctx);
-    q.persistent = (nk % 6 == 0 && slots_per_xcd * 8 > cus) ? 1 : 0;
-    const unsigned grid = (unsigned)(q.persistent ? std::min(slots_per_xcd, cus / 8) * 8 : slots_per_xcd * 8);
+    q.persistent = (nk % 6 == 0 && run_max * 8 > cus) ? 1 : 0;
+    if (getenv("SI_G256_PERSIST")) q.persistent = q.persistent && atoi(getenv("SI_G256_PERSIST")) != 0;      // experiment
+    const unsigned grid = (unsigned)(q.persistent ? std::min(run_max, cus / 8) * 8 : run_max * 8);
     const double macs = (double)p.nseg * p.M * p.N * (double)p.K;
     const double outs = (double)p.nseg * p.M * p.N;
     const double bytes = 2.0 * p.nseg * ((double)p.M * p.lda + (p.K - p.lda > 0 ? p.K - p.lda : 0)) + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0)) + 2.0 * p.N * p.K;

@@ -26,6 +26,17 @@
 // launcher's rule (rounds x (BM + 24)) picks 128 / 128 / 64 / 128 / 96 / 64 / 96 for these: 194 -> 174 us per
 // transformer layer.
 //
+// What bounds it (rocprofv3 counters, profiles/r03_lingemm_pmc.txt): the vector-memory path.  A 128 x 128 tile draws 32 KB of
+// operands from L2 per 2.1 MFLOP; at the measured rate that is 45 GB/s per CU (66-73 have been seen at best), the texture
+// addresser is stalled by the L1 45 % of the time, SQ_VMEM_TA_*_FIFO_FULL 18-20 % of the wave cycles, matrix pipe busy 0.29.
+// Two experiments confirmed it: a form with the A operand fetched straight into registers in the MFMA layout (half the LDS
+// staging, a three-deep W ring, the fragments of the next chunk requested before the barrier, the epilogue from the
+// accumulators) and a 13-operation erf instead of libm's erff in the epilogue both left every shape's time unchanged
+// within 2 %.  The lever is bytes per flop: gemm256.hip (256 x 256 tiles, 7.8 KB per MFLOP) takes the shapes whose tiles fill
+// the chip; this kernel keeps the rest.  Both order every output's sum identically (K in steps of 32, the same MFMA with the
+// same operand roles, the same epilogue arithmetic), so their results are BIT-IDENTICAL and the choice between them may
+// depend on the batch size without a clip's result depending on it.
+//
 // Structure (as respair_wide.hip): one 4-wave workgroup per BM x 128 tile (BM = 128 below), two workgroups per CU.  K chunks of 64
 // stream global -> registers -> LDS through a double buffer with the stores spread behind the MFMA blocks; one barrier
 // per chunk.  Orientation D^T = W * A^T: a lane holds one output row (column l & 15) and four consecutive output
@@ -44,7 +55,6 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float lg_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 constexpr int LG_BN = 128, LG_BK = 64, LG_NT = 256;
 constexpr int LG_ROWB = LG_BK * 2;                                     // 128-byte LDS rows
@@ -81,7 +91,7 @@ __device__ __forceinline__ void lg_epilogue(const LinGemmParams& p, char* smem, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float x = v[e] + bv[e];
-            if (gelu) x = lg_gelu(x);
+            if (gelu) x = si_gelu_fast(x);
             v[e] = x;
         }
         if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
@@ -227,248 +237,6 @@ __global__ __launch_bounds__(LG_NT, 2) void lingemm_kernel(const LinGemmParams p
     lg_epilogue<BM>(p, smem, acc, tid, wm0, wn0, r16, kg, seg, m0, n0);
 }
 
-// ------------------------------------------------------------------------------------------------ lingemm2: A operand from registers
-// Second form of the same GEMM, for the tall tiles (BM = 64 MT rows, MT = 2): the four waves sit 4 x 1, wave w owns rows
-// [16 MT w, 16 MT (w + 1)) x ALL 128 columns, so
-//   * the activation (A) fragments are PRIVATE to a wave: they go global -> registers directly in the MFMA operand layout
-//     and never touch LDS.  Within a 64-deep K chunk the k order is permuted (k-step s of lane group kg takes the original
-//     k = 16 kg + 8 s + [0, 8), for BOTH operands), so a lane's two fragments of a chunk are 32 CONTIGUOUS bytes of its row;
-//   * only the weights (W) are staged: half the ds_write traffic of the 2 x 2 form (the VGPR -> LDS path and the LDS array
-//     were both saturated there at the MFMA rate: 16 reads + 8 writes of 1 KB per 32 MFMAs and wave), 16 KB per buffer, so a
-//     THREE-deep ring fits twice per CU and the fragments of chunk c + 1's first k-step are requested before chunk c's
-//     barrier: no MFMA waits on LDS latency behind a barrier;
-//   * the epilogue runs from the accumulators (a lane holds 4 consecutive columns of one row per 16 x 16 tile: 64 contiguous
-//     bytes per row and store instruction in fp32; for bf16 lanes l and l + 16 trade halves of a column-tile pair and store
-//     16 bytes each): no fp32 LDS image, no barriers, waves retire independently.
-__device__ __forceinline__ int lg2_pchunk(int g) { return ((g & 1) << 2) | (g >> 1); }     // global 16-byte chunk g = 2 kg + s of a row -> LDS chunk 4 s + kg
-
-// Abramowitz-Stegun 7.1.26: |erf error| <= 1.5e-7 -- below one fp32 ulp of the gelu for |x| >= 1 and far below the bf16
-// rounding every consumer of these outputs applies; 13 VALU operations instead of libm's ~31 with two divergent branches
-// (the erff epilogue was a quarter of a 128 x 128 x 768 tile's time).
-__device__ __forceinline__ float lg_erf_fast(float x) {
-    const float ax = __builtin_fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
-    const float r = fmaf(-poly, e, 1.0f);
-    return __builtin_copysignf(r, x);
-}
-__device__ __forceinline__ float lg_gelu_fast(float x) { return 0.5f * x * (1.0f + lg_erf_fast(x * 0.70710678118654752440f)); }
-
-template <int MT>
-__global__ __launch_bounds__(LG_NT, 2) void lingemm2_kernel(const LinGemmParams p) {
-    constexpr int BM = 64 * MT;
-    constexpr int NTW = 8;                                             // 16-column tiles per wave: all 128 columns
-    extern __shared__ __attribute__((aligned(16))) char smem[];       // [3][128 x 64] bf16: the W ring
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r16 = lane & 15, kg = lane >> 4;
-
-    const int ntn = p.N / LG_BN;
-    const int mtiles = (p.M + BM - 1) / BM;
-    int tile = blockIdx.x;
-    if (p.xcd_rows > 0) {                                              // XCD-aware order, as lingemm_kernel
-        const int xcd = tile & 7, slot = tile >> 3;
-        const int mtx = xcd + 8 * (slot / ntn);
-        if (mtx >= p.xcd_rows) return;
-        tile = mtx * ntn + slot % ntn;
-    }
-    const int mt = tile / ntn;
-    const int seg = mt / mtiles;
-    const int m0 = (mt - seg * mtiles) * BM;
-    const int n0 = (tile - mt * ntn) * LG_BN;
-    const int wrow0 = wave * 16 * MT;
-
-    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.x16), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0, p.w_bytes, 0x00020000);
-    // A: lane (r16, kg) of row tile i reads bytes [128 c + 32 kg, + 32) of row m0 + wrow0 + 16 i + r16
-    const int a_voff = (int)(((long)seg * p.x_seg_stride + (long)(m0 + wrow0 + r16) * p.lda) * 2) + kg * 32;
-    const int a_step = p.lda * 2 * 16;
-    // W staging: thread (sc, sr0) moves global chunk sc of rows sr0 + 32 i into LDS chunk lg2_pchunk(sc) (swizzled)
-    const int sc = tid & 7, sr0 = tid >> 3;
-    const int w_voff = ((n0 + sr0) * p.Cin) * 2 + sc * 16;
-    const int w_step = p.Cin * 2 * 32;
-    const int cpt = p.Cin / LG_BK;
-    const int s_off = sr0 * LG_ROWB + ((lg2_pchunk(sc) << 4) ^ lg_swz(sr0));      // rows sr0 + 32 i share the swizzle term of sr0
-    int preW[NTW];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-        const int n = 16 * j + r16;
-        preW[j] = n * LG_ROWB + (lg_swz(n) ^ (kg << 4));
-    }
-
-    u32x4 ra[3][MT][2], rw[3][4];
-    bf16x8 wf[2][NTW];                                                 // W fragments of the two k-steps of a chunk
-    f32x4 acc[MT][NTW];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nchunks = p.K / LG_BK;
-    const int last = nchunks - 1;
-    auto issue_a = [&](auto set, int c) {
-        constexpr int S = decltype(set)::value;
-        const int soff = __builtin_amdgcn_readfirstlane((c < last ? c : last) * LG_BK * 2);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            ra[S][i][0] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff + i * a_step, soff, 0);
-            ra[S][i][1] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_voff + i * a_step + 16, soff, 0);
-        }
-    };
-    auto issue_w = [&](auto set, int c0) {
-        constexpr int S = decltype(set)::value;
-        const int c = c0 < last ? c0 : last;
-        const int tap = c / cpt;
-        const int soff = __builtin_amdgcn_readfirstlane((int)(((long)tap * p.w_tap_stride + (long)(c - tap * cpt) * LG_BK) * 2));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rw[S][i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff + i * w_step, soff, 0);
-    };
-    auto store_w = [&](auto set, int b) {
-        constexpr int S = decltype(set)::value;
-        char* buf = smem + b * LG_WTILE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(buf + s_off + i * 32 * LG_ROWB) = rw[S][i];
-    };
-    auto load_w = [&](int ks, int b) {
-        const char* buf = smem + b * LG_WTILE;
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(buf + (preW[j] ^ (ks * 64)));
-    };
-    auto mma = [&](auto set, int ks, int j0, int j1) {
-        constexpr int S = decltype(set)::value;
-#pragma unroll
-        for (int j = j0; j < j1; ++j)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], __builtin_bit_cast(bf16x8, ra[S][i][ks]), acc[i][j], 0, 0, 0);
-    };
-    typedef std::integral_constant<int, 0> S0;
-    typedef std::integral_constant<int, 1> S1;
-    typedef std::integral_constant<int, 2> S2;
-
-    // prologue: A chunks 0, 1; W chunks 0, 1 into the ring, chunk 2 in flight
-    issue_w(S0{}, 0);
-    issue_a(S0{}, 0);
-    issue_w(S1{}, 1);
-    issue_a(S1{}, 1);
-    issue_w(S2{}, 2);
-    store_w(S0{}, 0);
-    store_w(S1{}, 1);
-    __syncthreads();
-    load_w(0, 0);
-    // Iteration c (u = c % 3): requests W chunk c + 3 (register set u, free since chunk c went to LDS in iteration c - 2) and A
-    // chunk c + 2; multiplies chunk c from LDS buffer u with the A registers of set u; stores W chunk c + 2 (set (c + 2) % 3)
-    // into buffer (c + 2) % 3, which every wave finished reading before the barrier of iteration c - 1; and reads the first
-    // fragments of chunk c + 1 (visible since that barrier) under its last MFMAs.  Loads are unconditional (clamped).
-    auto step = [&](auto su, auto su1, auto su2, int c) {
-        constexpr int U = decltype(su)::value, U1 = decltype(su1)::value, U2 = decltype(su2)::value;
-        issue_w(su, c + 3);
-        issue_a(su2, c + 2);
-        load_w(1, U);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        mma(su, 0, 0, NTW);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        store_w(su2, U2);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        mma(su, 1, 0, NTW / 2);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_w(0, U1);                                                 // overwrites wf[0]: its MFMAs are done
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        mma(su, 1, NTW / 2, NTW);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-    };
-    for (int c = 0; c < nchunks; c += 3) {
-        step(S0{}, S1{}, S2{}, c);
-        if (c + 1 < nchunks) step(S1{}, S2{}, S0{}, c + 1);
-        if (c + 2 < nchunks) step(S2{}, S0{}, S1{}, c + 2);
-    }
-
-    // ---- epilogue from the accumulators: lane (r16, kg) holds row wrow0 + 16 i + r16, columns 16 j + 4 kg + [0, 4)
-    const bool gelu = p.act == SI_ACT_GELU;
-    const long obase = (long)seg * p.o_seg_stride;
-    f32x4 bv[NTW];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {                                                      // conditions hoisted out of the unrolled loops (see gemm256.hip)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * j + 4 * kg);
-    }
-    const bool has_res = p.res != nullptr;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int m = m0 + wrow0 + 16 * i + r16;
-        const bool live = m < p.M;
-        const long orow = obase + (long)(live ? m : p.M - 1) * p.ldo + n0;             // dead rows read row M - 1 and store nothing
-        f32x4 rv[NTW];
-        if (has_res) {
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) rv[j] = *reinterpret_cast<const f32x4*>(p.res + orow + 16 * j + 4 * kg);
-        }
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            f32x4 v = acc[i][j] + bv[j];
-            if (gelu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = lg_gelu_fast(v[e]);
-            }
-            if (has_res) v += rv[j];
-            if (p.out && live) *reinterpret_cast<f32x4*>(p.out + orow + 16 * j + 4 * kg) = v;
-            acc[i][j] = v;
-        }
-        if (p.out16) {
-            // bf16: lanes l and l + 16 trade halves of a column-tile pair (v_permlane16_swap: odd 16-lane rows of the first
-            // operand <-> even rows of the second): an even kg then owns columns 4 kg + [0, 8) of tile 2 t, an odd one columns
-            // 4 (kg - 1) + [0, 8) of tile 2 t + 1 -- 16 bytes per lane, 64 contiguous bytes per row and store instruction
-#pragma unroll
-            for (int t = 0; t < NTW / 2; ++t) {
-                u32x2 p0 = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[i][2 * t], bf16x4));
-                u32x2 p1 = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[i][2 * t + 1], bf16x4));
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const auto r = __builtin_amdgcn_permlane16_swap(p0[q], p1[q], false, false);
-                    p0[q] = r[0]; p1[q] = r[1];
-                }
-                const int col = 16 * (2 * t + (kg & 1)) + 4 * (kg & ~1);
-                if (live) *reinterpret_cast<u32x4*>(p.out16 + orow + col) = u32x4{p0[0], p0[1], p1[0], p1[1]};
-            }
-        }
-    }
-}
-
-template <int MT>
-static int lingemm2_launch(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
-    constexpr int BM = 64 * MT;
-    const size_t lds = 3 * (size_t)LG_WTILE;
-    if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(lingemm2_kernel<MT>), lds)) return rc;
-    const int mtiles = (p.M + BM - 1) / BM;
-    const bool xcd = (double)p.N * p.K * 2.0 <= 3.6e6;                 // as lingemm_launch
-    LinGemmParams q = p;
-    const int rows_total = p.nseg * mtiles;
-    q.xcd_rows = xcd ? rows_total : 0;
-    const unsigned grid = (unsigned)((xcd ? (rows_total + 7) / 8 * 8 : rows_total) * (p.N / LG_BN));
-    const double macs = (double)p.nseg * p.M * p.N * (double)p.K;
-    const double outs = (double)p.nseg * p.M * p.N;
-    const double bytes = 2.0 * p.nseg * ((double)p.M * p.lda + (p.K - p.lda > 0 ? p.K - p.lda : 0)) + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0)) + 2.0 * p.N * p.K;
-    char name[48];
-    snprintf(name, sizeof(name), "lingemm_bf16_%dx128r", BM);          // "r": the A operand from registers
-    si_prof_begin(ctx, si_prof_shape_name(name, p.M * (long)p.nseg, p.N, p.K), 2.0 * macs, bytes, st);
-    hipLaunchKernelGGL(lingemm2_kernel<MT>, dim3(grid), dim3(LG_NT), lds, st, q);
-    si_prof_end(ctx, st);
-    SI_HIP_CHECK(hipGetLastError());
-    return SI_OK;
-}
-
 template <int BM>
 static int lingemm_launch(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     const size_t lds = std::max<size_t>(2 * ((size_t)BM * LG_ROWB + LG_WTILE), (size_t)BM * 512);   // operand double buffer / fp32 output image
@@ -500,12 +268,10 @@ int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     if (p.N % LG_BN || p.Cin % LG_BK || p.K % LG_BK || p.K != p.ntaps * p.Cin || p.ldo % 4 || p.lda % 8 || p.M <= 0 || p.nseg <= 0) return 1;
     if (p.x_bytes <= 0 || p.w_bytes <= 0 || (long)p.nseg * p.x_seg_stride * 2 + (long)(p.M + 128) * p.lda * 2 >= (1L << 31)) return 1;
     if (!p.out && !p.out16) return si_fail(ctx, SI_EINVAL, "lingemm: no output");
-#ifndef LG_NO_256
     {
-        const int rc = si_launch_gemm256(ctx, p, st);                  // 256 x 256 tiles where they fill the chip
+        const int rc = si_launch_gemm256(ctx, p, st);                  // 256 x 256 tiles where they fill the chip (bit-identical results)
         if (rc <= 0) return rc;
     }
-#endif
     // Tile height: the workgroup slots are 2 per CU; a launch takes ceil(tiles / slots) rounds of a tile's time, which
     // grows with BM (plus a fixed part: prologue, epilogue).  Pick the BM with the smallest rounds x (BM + fixed).
     int bm = 128;
@@ -520,9 +286,5 @@ int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     }
     if (bm == 64) return lingemm_launch<64>(ctx, p, st);
     if (bm == 96) return lingemm_launch<96>(ctx, p, st);
-#ifdef LG_OLD_128
     return lingemm_launch<128>(ctx, p, st);
-#else
-    return lingemm2_launch<2>(ctx, p, st);
-#endif
 }

@@ -32,3 +32,13 @@ for r in sorted(rows, key=lambda r: -r["ms"]):
         gemm += r["ms"] / passes
     print(f"  {r['name']:<44} {n:5.1f} x {1e3 * r['ms'] / r['launches']:8.1f} us = {r['ms'] / passes:7.3f} ms  {r['flops'] / r['ms'] / 1e9 if r['ms'] else 0:7.1f} TFLOP/s")
 print(f"  GEMM kernels together: {gemm:.3f} ms per pass; checksum {float(f.double().abs().sum()):.6e}")
+if "timeline" in os.environ.get("SI_HIP_LIB", ""):
+    import ctypes
+    out = (ctypes.c_ulonglong * 24)()
+    eng.ctx.lib.si_debug_g256_timeline(out, 1)
+    for c, nm in enumerate(("conv K=1536", "N=2304 (QKV)", "N=3072 (FFN1)", "other")):
+        v = out[6 * c:6 * c + 6]
+        if v[4]:
+            print(f"  gemm256 timeline, {nm}: {v[3]} tiles on {v[4]} workgroup launches; per workgroup: prologue {v[0] / v[4] * 0.01:.2f} us, "
+                  f"K loops {v[1] / v[4] * 0.01:.2f} us ({v[1] / max(v[3], 1) * 0.01:.2f} per tile), epilogues {v[2] / v[4] * 0.01:.2f} us "
+                  f"({v[2] / max(v[3], 1) * 0.01:.2f} per tile), whole kernel {v[5] / v[4] * 0.01:.2f} us")

@@ -10,10 +10,18 @@ from speech_inpainting_amd.engine import InpaintingEngine
 h, v = HubertArch.tiny(), VocoderArch.v1()
 eng = InpaintingEngine(h, v, 20, "cuda:0", "fp32", "fp16").load_state(synth.synth_hubert_state(h), synth.synth_generator_state(v), synth.synth_codebook(20))
 mel = synth.synth_mel(32, 200, 80, 5).cuda()
-for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
+passes = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+for _ in range(2):
     w = eng.vocode(mel, stretch=True)
 torch.cuda.synchronize()
-print("ok", float(w.float().abs().mean()))
+eng.ctx.profile_start(200 * passes)
+for _ in range(passes):
+    w = eng.vocode(mel, stretch=True)
+torch.cuda.synchronize()
+rows = eng.ctx.profile_stop()
+print(f"vocoder alone, B=32: {sum(r['ms'] for r in rows) / passes:.3f} ms per pass in kernels ({os.environ.get('SI_HIP_LIB', 'default lib')}); checksum {float(w.double().abs().sum()):.9e}")
+for r in sorted(rows, key=lambda r: -r["ms"]):
+    print(f"  {r['name']:<28} {r['launches'] / passes:5.1f} x {1e3 * r['ms'] / r['launches']:8.1f} us = {r['ms'] / passes:7.3f} ms  {r['flops'] / r['ms'] / 1e9 if r['ms'] else 0:7.1f} TFLOP/s")
 if "timeline" in os.environ.get("SI_HIP_LIB", ""):
     import ctypes
     out = (ctypes.c_ulonglong * 20)()

@@ -776,6 +776,11 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     WaveNormParams wp{wav, mask_start, mask_len, B, N, e.L[1], d.conv_dim[0], d.conv_kernel[0], d.conv_stride[0], normalize, valid_len, norm_eps, pre_add};
     if ((rc = si_launch_wave_stats(ctx, wp, stats, st))) return rc;
     if (valid_len && (rc = si_launch_frame_lengths(ctx, valid_len, B, d.num_conv, d.conv_kernel, d.conv_stride, e.T, vframes, st))) return rc;
+    // layer-norm flavour (HuBERT-large) in bf16 mode: every conv is followed by LayerNorm + GELU over its 512 channels; the
+    // LayerNorm writes ONLY the bf16 operand of the next conv (the rounding that conv would apply while staging), into the
+    // other buffer (its bf16 rows would overlap unread fp32 rows of its own input), so that the convolutions run on the
+    // dedicated bf16 GEMM kernels (lingemm / gemm256) like the group-norm flavour's; the last one writes the fp32 features.
+    const bool l16 = ctx->opt_enc_opready && d.encoder_math == SI_MATH_BF16 && d.feat_norm_layer && d.num_conv >= 2;
     if (!d.feat_norm_layer) {
         // group-norm flavour in bf16 mode: the conv chain runs on operand-ready bf16 activations (conv0 and convs 1..n-2
         // write ONLY the bf16 operand of their single consumer; the last conv writes fp32 for the LayerNorm that follows)
@@ -783,7 +788,8 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
                                        c16 ? cb16[0] : nullptr);
     } else {
         rc = si_launch_conv0_affine(ctx, wp, stats, wf(ctx, L.conv0_w), d.conv_bias ? wf(ctx, L.conv0_bias) : nullptr, affine, cbuf[0], st);
-        if (!rc) rc = si_launch_layernorm(ctx, cbuf[0], nullptr, wf(ctx, L.conv0_g), wf(ctx, L.conv0_b), cbuf[0], (long)B * e.L[1], d.conv_dim[0], 1e-5f, 1, st);
+        if (!rc) rc = si_launch_layernorm(ctx, cbuf[0], nullptr, wf(ctx, L.conv0_g), wf(ctx, L.conv0_b), l16 ? nullptr : cbuf[0], (long)B * e.L[1], d.conv_dim[0],
+                                          1e-5f, 1, st, l16 ? cb16[1] : nullptr);
     }
     if (rc) return rc;
     // A2: strided convs as tap-GEMMs
@@ -796,12 +802,21 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
             p.x = nullptr; p.x16 = cb16[cur];
             if (i + 1 < d.num_conv) { p.out = nullptr; p.out16 = cb16[cur ^ 1]; p.out16_slope = 1.f; }
         }
+        if (l16) { p.x = nullptr; p.x16 = cb16[1]; p.out = cbuf[0]; }          // bf16 in from buffer 1, fp32 out to buffer 0
         p.nseg = B; p.Lin = e.L[i]; p.M = e.L[i + 1]; p.ldx = d.conv_dim[i - 1]; p.x_seg_stride = (long)e.L[i] * d.conv_dim[i - 1];
         p.stride = d.conv_stride[i]; p.ldo = d.conv_dim[i]; p.o_seg_stride = (long)e.L[i + 1] * d.conv_dim[i];
         p.olimit = p.o_seg_stride;
         p.act = d.feat_norm_layer ? SI_ACT_NONE : SI_ACT_GELU;
         p.lingemm = ctx->opt_enc_lingemm;
         if ((rc = si_launch_tapgemm(ctx, c.g.math, p, st))) return rc;
+        if (l16) {
+            const bool last = i + 1 == d.num_conv;
+            if ((rc = si_launch_layernorm(ctx, cbuf[0], nullptr, wf(ctx, c.ln_g), wf(ctx, c.ln_b), last ? cbuf[1] : nullptr, (long)B * e.L[i + 1], d.conv_dim[i],
+                                          1e-5f, 1, st, last ? nullptr : cb16[1])))
+                return rc;
+            cur = 1;
+            continue;
+        }
         cur ^= 1;
         if (d.feat_norm_layer &&
             (rc = si_launch_layernorm(ctx, cbuf[cur], nullptr, wf(ctx, c.ln_g), wf(ctx, c.ln_b), cbuf[cur], (long)B * e.L[i + 1], d.conv_dim[i], 1e-5f, 1, st)))

@@ -124,7 +124,7 @@ int si_launch_conv0_affine(si_ctx* ctx, const WaveNormParams& p, const double* s
 size_t si_conv0_partials_bytes(int B, int N);
 
 // y = LN(x [+ add]) * gamma + beta over the last dim C (rows x C), optional GELU afterwards
-// y16 (optional): bf16 copy of y for a bf16 GEMM consumer
+// y16 (optional): bf16 copy of y for a bf16 GEMM consumer; y may then be NULL (bf16 output only)
 int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const float* gamma, const float* beta, float* y,
                         long rows, int C, float eps, int gelu, hipStream_t st, unsigned short* y16 = nullptr);
 

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                     float t = (v[j][e] - mean) * rstd * g[e] + bt[e];
                     o[e] = GELU ? gelu_erf(t) : t;
                 }
-                *reinterpret_cast<f32x4*>(yr + i) = o;
+                if (y) *reinterpret_cast<f32x4*>(yr + i) = o;           // (y16 alone: the only consumer is a bf16 GEMM)
                 // operand-ready copy for a bf16 GEMM consumer (round-to-nearest-even, as the GEMM's own staging would)
                 if (y16) *reinterpret_cast<bf16x4*>(y16 + row * C + i) = __builtin_convertvector(o, bf16x4);
             }
@@ -400,7 +400,8 @@ int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const flo
     // per CU and one row per wave: 0.40 / 0.35 / 0.36 / 0.37 ms per step)
     constexpr int per_cu = 4;
     dim3 grid((unsigned)std::min<long>((rows + 3) / 4, (long)si_num_cus(ctx) * per_cu));
-    si_prof_begin(ctx, "layernorm", 8.0 * rows * C, 8.0 * rows * C, st);
+    if (!y && !y16) return si_fail(ctx, SI_EINVAL, "layernorm: no output");
+    si_prof_begin(ctx, "layernorm", 8.0 * rows * C, (4.0 + (add ? 4.0 : 0.0) + (y ? 4.0 : 0.0) + (y16 ? 2.0 : 0.0)) * rows * C, st);
     if (gelu) hipLaunchKernelGGL(layernorm_kernel<true>, grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
     else hipLaunchKernelGGL(layernorm_kernel<false>, grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
     si_prof_end(ctx, st);

@@ -25,6 +25,8 @@ def family(kernel_name: str) -> str:
     m = re.search(r"lingemm_kernel<(\d+)>", kernel_name)
     if m:      # bench.py's family name: lingemm_bf16_<BM>x128
         return f"lingemm_bf16_{m.group(1)}x128"
+    if "gemm256_kernel" in kernel_name:
+        return "gemm256_bf16"
     if "attention_bf16" in kernel_name:
         return "attention_bf16"
     m = re.search(r"reschain_kernel<(\w+)>", kernel_name)

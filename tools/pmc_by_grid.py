@@ -35,4 +35,7 @@ for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["_us"]):
         line += f"; clock {gui / 8 / (a['_us'] * 1e-6) / 1e9:.2f} GHz"
         if "SQ_VALU_MFMA_BUSY_CYCLES" in a:
             line += f"; mfma busy {a['SQ_VALU_MFMA_BUSY_CYCLES'] / (gui / 8 * 1024):.3f}"
-    print(line)
+    try:
+        print(line)
+    except BrokenPipeError:
+        break

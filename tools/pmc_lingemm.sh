@@ -1,8 +1,18 @@
-cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-run() { tag=$1; shift; rm -rf /tmp/p_$tag; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/p_$tag -- python3 $R/tools/exp_encoder_only.py 2 > /tmp/p_$tag.log 2>&1 || { echo "pass $tag failed"; tail -3 /tmp/p_$tag.log; return; }; python3 $R/tools/pmc_by_grid.py /tmp/p_$tag/*/*_counter_collection.csv /tmp/p_$tag/*/*_kernel_trace.csv lingemm2 | head -3 > $R/gpurun_out/r3_lg_pmc_$tag.txt; }
-run B SQ_WAVE_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE
-run C SQ_WAVE_CYCLES SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_VALU_MFMA_COEXEC_CYCLES
-run D TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE
-run E TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCR_TCP_STALL_CYCLES_sum
-run F TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_TAG_STALL_sum
-cat $R/gpurun_out/r3_lg_pmc_*.txt
+# rocprofv3 counter passes over the bf16 encoder alone (tools/exp_encoder_only.py, B = 32 x 4 s): the 128-row GEMM kernel on
+# every shape (SI_ENC_GEMM256=0) and the 256 x 256-tile kernel on the shapes the rule gives it, per kernel and grid size
+# (the launches of one instantiation on different shapes have different grids).  Separate --pmc passes, --kernel-trace only.
+# Run on the GPU box from the repo root; writes gpurun_out/r03_lingemm_pmc.txt.
+cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/r03_lingemm_pmc.txt; : > $out
+run() { tag=$1; want=$2; shift 2; rm -rf /tmp/p_$tag; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/p_$tag -- python3 $R/tools/exp_encoder_only.py 2 > /tmp/p_$tag.log 2>&1 || { echo "pass $tag failed" >> $out; tail -3 /tmp/p_$tag.log >> $out; return; }; echo "== $tag: $*" >> $out; python3 $R/tools/pmc_by_grid.py /tmp/p_$tag/*/*_counter_collection.csv /tmp/p_$tag/*/*_kernel_trace.csv "$want" >> $out 2>&1; }
+for mode in 0 1; do
+  export SI_ENC_GEMM256=$mode
+  if [ $mode = 0 ]; then want="lingemm_kernel<128>"; else want="gemm256"; fi
+  echo "######## SI_ENC_GEMM256=$mode ($want)" >> $out
+  run wave_$mode "$want" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
+  run issue_$mode "$want" SQ_WAVE_CYCLES SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU
+  run ta_$mode "$want" TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE
+  run tcp_$mode "$want" TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCR_TCP_STALL_CYCLES_sum
+  run tcc_$mode "$want" TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_TAG_STALL_sum
+done
+unset SI_ENC_GEMM256
+wc -l $out

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -51,7 +52,13 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
     constexpr int CPR = C / 8;                                         // 16-byte chunks per row
     constexpr int KS = C / 32;                                         // MFMA k-steps (K = 32) per tap
     constexpr int TN = C / 16;                                         // 16-column tiles per wave
-    constexpr int YBYTES = (R1 + RPN_HALO) * ROWB;
+    // C = 64: the activation / intermediate rows are PADDED to 160 bytes and not swizzled (enumerated over the hardware's lane
+    // groups: operand reads and staging stores stay conflict-free, the traded epilogue stores become 2-way), so a tap's
+    // row offset is a plain scalar add and the four row tiles of a wave sit at immediate offsets: 1 VALU op per k-step
+    // where the XOR swizzle took 4 per fragment.  C = 32 keeps the swizzled 64-byte rows (two workgroups per CU must fit).
+    constexpr int YPAD = C == 64 ? 32 : 0;
+    constexpr int YS = ROWB + YPAD;                                    // bytes from one activation row to the next
+    constexpr int YBYTES = (R1 + RPN_HALO) * YS;
     constexpr int WBYTES = TPS * C * ROWB;                             // one slab: TPS taps x [C n][C ci]
     constexpr int WSLOTS = (WBYTES / 16 + NT - 1) / NT;
     constexpr int YRPP = NT / CPR;                                     // rows per staging pass
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
         if ((i + 1) * YRPP <= R1 || r < R0) {                           // rows < R1 always exist: no branch around their loads
             f16x8 h = __builtin_bit_cast(f16x8, ry[i]);
             h = __builtin_elementwise_max(h, h * (_Float16)0.1f);     // leaky-ReLU(0.1) = max(x, 0.1 x), packed
-            *reinterpret_cast<f16x8*>(Ys + r * ROWB + ((yc << 4) ^ rpn_swz<ROWB>(r))) = h;
+            *reinterpret_cast<f16x8*>(Ys + r * YS + (YPAD ? yc << 4 : (yc << 4) ^ rpn_swz<ROWB>(r))) = h;
         }
     }
     __syncthreads();
@@ -156,31 +163,34 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
         }
     };
     init_acc(Bs);
-    int lin0[4], preW[TN];
+    // row tile i of the activations is 16 * i rows (an immediate) behind row tile 0; channel tile j of a weight slab is 16 * j
+    // rows behind tile 0 with the same swizzle term (16 rows keep it), and k-step 1 flips byte bit 6 of the swizzled chunk
+    const int lin0 = (wm0 + r16) * YS + (kg << 4);
+    int preW[KS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lin0[i] = (wm0 + 16 * i + r16) * ROWB + (kg << 4);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = 16 * j + r16;
-        preW[j] = n * ROWB + (rpn_swz<ROWB>(n) ^ (kg << 4));          // + tap * C * ROWB: C rows keep the swizzle term (C % 16 == 0)
-    }
+    for (int ks = 0; ks < KS; ++ks) preW[ks] = r16 * ROWB + (rpn_swz<ROWB>(r16) ^ (kg << 4) ^ (ks * 64));
     // one slab = `ntap` taps x KS k-steps; step q = tap * KS + ks.  Fragments are double-buffered in registers: the reads
     // of step q + 1 are issued before the MFMAs of step q (clamped to the last step: a harmless re-read).
     auto compute = [&](int tap0, bool second, int ntap, const char* Wc) {
         const int nsteps = ntap * KS;
-        auto load = [&](f16x8 (&y)[4], f16x8 (&w)[TN], int q) {
-            const int tl = KS == 1 ? q : q >> 1, ks = KS == 1 ? 0 : q & 1;
-            // linear byte offset of (row, k group) plus the step's scalar part, then the swizzle as an XOR of address bits
-            // (row bits 0-2 -> byte bits 4-6 on 128-byte rows, row bits 1-2 -> byte bits 4-5 on 64-byte rows): 3 VALU ops per read
-            // instead of 6 -- the VALU shares the SIMD's issue port with the MFMAs (C = 64: -4 % same-box)
-            const int soff = (second ? tap0 + tl : (tap0 + tl) * d) * ROWB + ks * 64;
+        auto load = [&](f16x8 (&y)[4], f16x8 (&w)[TN], int q, const int ks) {   // ks == q % KS, passed as a literal
+            const int tl = KS == 1 ? q : q >> 1;
+            // linear byte offset of (row, k group) plus the step's scalar part; on swizzled rows (C = 32) the swizzle is an XOR
+            // of address bits (row bits 1-2 -> byte bits 4-5 on 64-byte rows).  The VALU shares the SIMD's issue port with the
+            // MFMAs, so every address op here is paid for in MFMA issue slots.
+            const int soff = (second ? tap0 + tl : (tap0 + tl) * d) * YS + ks * 64;
+            const int lin = lin0 + soff;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int lin = lin0[i] + soff;
-                y[i] = *reinterpret_cast<const f16x8*>(Ys + (lin ^ ((lin >> 3) & (ROWB == 128 ? 0x70 : 0x30))));
+                if constexpr (YPAD) y[i] = *reinterpret_cast<const f16x8*>(Ys + lin + i * (16 * YS));
+                else {
+                    const int l = lin + i * (16 * YS);
+                    y[i] = *reinterpret_cast<const f16x8*>(Ys + (l ^ ((l >> 3) & 0x30)));
+                }
             }
+            const char* wp = Wc + tl * (C * ROWB) + preW[ks];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) w[j] = *reinterpret_cast<const f16x8*>(Wc + tl * (C * ROWB) + (preW[j] ^ (ks * 64)));
+            for (int j = 0; j < TN; ++j) w[j] = *reinterpret_cast<const f16x8*>(wp + j * (16 * ROWB));
         };
         auto mma = [&](const f16x8 (&y)[4], const f16x8 (&w)[TN]) {
 #pragma unroll
@@ -189,15 +199,15 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], y[i], acc[i][j], 0, 0, 0);
         };
         f16x8 ya[4], wa[TN], yb[4], wb[TN];
-        load(ya, wa, 0);
+        load(ya, wa, 0, 0);
         for (int q = 0; q < nsteps; q += 2) {
-            load(yb, wb, q + 1 < nsteps ? q + 1 : nsteps - 1);
+            load(yb, wb, q + 1 < nsteps ? q + 1 : nsteps - 1, KS - 1);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
             mma(ya, wa);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            load(ya, wa, q + 2 < nsteps ? q + 2 : nsteps - 1);
+            load(ya, wa, q + 2 < nsteps ? q + 2 : nsteps - KS, 0);         // (an even step: the k-step stays a compile-time constant)
             __builtin_amdgcn_sched_barrier(0);
             if (q + 1 < nsteps) {
                 __builtin_amdgcn_s_setprio(1);
@@ -227,13 +237,17 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
             // ---- phase-1 epilogue: leaky-ReLU (the bias is in the accumulators), zero outside the clip, fp16, over the activation
             //      tile, as 16-byte stores after lanes l and l + 16 traded chunk halves (respair_wide.hip, reschain.hip: the
             //      8-byte stores of the accumulator layout are 4-way bank conflicted on these rows)
+            // (a tile whose intermediate rows all lie inside the clip -- all but the first and last of a clip -- skips the factor:
+            //  the branch is uniform and the epilogue's VALU work is time no MFMA overlaps)
+            auto epi1 = [&](auto edge_tag) {
+                constexpr bool EDGE = decltype(edge_tag)::value;
 #pragma unroll
             for (int ip = 0; ip < 2; ++ip) {
                 float inside[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int grow = t_row0 + wm0 + 16 * (2 * ip + u) + r16;
-                    inside[u] = (grow >= 0 && grow < p.L) ? 1.f : 0.f;         // as a factor: no branch per element
+                    inside[u] = (!EDGE || (grow >= 0 && grow < p.L)) ? 1.f : 0.f;   // as a factor: no branch per element
                 }
                 const int ms = wm0 + 16 * (2 * ip + (kg & 1)) + r16;           // the row this lane stores after the trade
 #pragma unroll
@@ -243,7 +257,7 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
                     for (int u = 0; u < 2; ++u) {
                         f16x4 hv;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(si_lrelu01(acc[2 * ip + u][j][e]) * inside[u]);   // saturating (MODE.FP16_OVFL)
+                        for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(EDGE ? si_lrelu01(acc[2 * ip + u][j][e]) * inside[u] : si_lrelu01(acc[2 * ip + u][j][e]));   // saturating (MODE.FP16_OVFL)
                         pk[u] = __builtin_bit_cast(u32x2, hv);
                     }
 #pragma unroll
@@ -252,9 +266,12 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
                         pk[0][q] = r[0]; pk[1][q] = r[1];
                     }
                     const int ch = 2 * j + (kg >> 1);                          // 16-byte chunk (8 channels) of the row
-                    *reinterpret_cast<u32x4*>(Ys + ms * ROWB + ((ch << 4) ^ rpn_swz<ROWB>(ms))) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+                    *reinterpret_cast<u32x4*>(Ys + ms * YS + (YPAD ? ch << 4 : (ch << 4) ^ rpn_swz<ROWB>(ms))) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
                 }
             }
+            };
+            if (t_row0 >= 0 && t_row0 + R1 <= p.L) epi1(std::false_type{});
+            else epi1(std::true_type{});
             init_acc(Bs + C);
         }
         if (s + 1 < NS) {
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
 template <int C, int R1, int WARPS_M, int TPS>
 static int respair_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t st) {
     const int BMo = R1 - (p.k - 1);
-    const size_t lds = (size_t)(R1 + RPN_HALO) * C * 2 + 2 * (size_t)TPS * C * C * 2 + 2 * (size_t)C * 4;
+    const size_t lds = (size_t)(R1 + RPN_HALO) * (C * 2 + (C == 64 ? 32 : 0)) + 2 * (size_t)TPS * C * C * 2 + 2 * (size_t)C * 4;
     auto kern = p.accumulate ? respair_kernel<C, R1, WARPS_M, TPS, true> : respair_kernel<C, R1, WARPS_M, TPS, false>;
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), lds)) return rc;
     // persistent workgroups: as many as are resident at once (two per CU for the 4-wave C = 32 form), each walking tiles

@@ -158,12 +158,7 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
     storeW(W1s);
     issueW(p.w2[0]);
 
-    int preW[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = 16 * j + r16;
-        preW[j] = n * RC_ROWB + (rc_swz(n) ^ (kg << 4));               // + tap * 2048: 32 rows keep the swizzle term
-    }
+    const int preW = r16 * RC_ROWB + (rc_swz(r16) ^ (kg << 4));        // + tap * 2048 + j * 1024: 16 rows keep the swizzle term
 
     f32x4 acc[RC_RT][2];                                               // [time tile i][channel tile j], transposed 16 x 16 tiles
     // the accumulators start from the bias of this lane's four consecutive channels (16 j + 4 kg ...): no add per element later
@@ -172,11 +167,12 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
 #pragma unroll
         for (int i = 0; i < RC_RT; ++i) { acc[i][0] = b0; acc[i][1] = b1v; }
     };
-    // Operand addresses: linear byte offset of (row, k group) plus the tap's row offset (a scalar), then the swizzle as an
-    // XOR of address bits: bits 7-8 (row bits 1-2) -> bits 4-5.  Three VALU ops per fragment read.
-    int lin0[RC_RT];
-#pragma unroll
-    for (int i = 0; i < RC_RT; ++i) lin0[i] = (wm0 + 16 * i + r16 + RC_MARG) * RC_ROWB + (kg << 4);
+    // Operand addresses: linear byte offset of (row, k group) of row tile 0 plus the tap's row offset (a scalar), then the
+    // swizzle as an XOR of address bits: bits 7-8 (row bits 1-2) -> bits 4-5.  Row tile i is 16 i rows = 1024 i bytes further:
+    // above every bit the swizzle reads or writes, so the six fragment reads of a tap share ONE swizzled address and differ
+    // in the instruction's immediate offset -- 4 VALU ops per tap instead of 24 (the VALU shares the SIMD's issue port with
+    // the MFMAs; the compiler does not find this form from per-tile addresses).
+    const int lin0 = (wm0 + r16 + RC_MARG) * RC_ROWB + (kg << 4);
     // lane (r16, kg) of accumulator tile (i, j): row wm0 + 16 i + r16, channels 16 j + 4 kg ... + 3 -> byte offset in a
     // swizzled 64-byte-row image whose row 0 is tile row -`shift`
     auto el_off = [&](int i, int j, int shift) {
@@ -191,14 +187,13 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
 #ifdef RC_ABLATE_READS                                                 // diagnostic build: results are garbage, timing only
             if (tap > 0) return;
 #endif
-            const int soff = (tap - c) * dd * RC_ROWB;
+            const int lin = lin0 + (tap - c) * dd * RC_ROWB;
+            const char* ap = As + (lin ^ ((lin >> 3) & 0x30));
 #pragma unroll
-            for (int i = 0; i < RC_RT; ++i) {
-                const int lin = lin0[i] + soff;
-                y[i] = *reinterpret_cast<const f16x8*>(As + (lin ^ ((lin >> 3) & 0x30)));
-            }
+            for (int i = 0; i < RC_RT; ++i) y[i] = *reinterpret_cast<const f16x8*>(ap + i * (16 * RC_ROWB));
+            const char* wp = Wc + tap * (RC_C * RC_ROWB) + preW;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) w[j] = *reinterpret_cast<const f16x8*>(Wc + tap * (RC_C * RC_ROWB) + preW[j]);
+            for (int j = 0; j < 2; ++j) w[j] = *reinterpret_cast<const f16x8*>(wp + j * (16 * RC_ROWB));
         };
         auto mma = [&](const f16x8 (&y)[RC_RT], const f16x8 (&w)[2]) {
 #ifdef RC_ABLATE_HALF                                                  // diagnostic build: only one wave per SIMD issues MFMAs

@@ -180,14 +180,11 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
             // MFMAs, so every address op here is paid for in MFMA issue slots.
             const int soff = (second ? tap0 + tl : (tap0 + tl) * d) * YS + ks * 64;
             const int lin = lin0 + soff;
+            // (swizzled rows: 16 rows further is 1024 bytes further, above every bit the swizzle touches -- one swizzled address
+            //  and immediate offsets, as in reschain.hip)
+            const char* yp = Ys + (YPAD ? lin : lin ^ ((lin >> 3) & 0x30));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if constexpr (YPAD) y[i] = *reinterpret_cast<const f16x8*>(Ys + lin + i * (16 * YS));
-                else {
-                    const int l = lin + i * (16 * YS);
-                    y[i] = *reinterpret_cast<const f16x8*>(Ys + (l ^ ((l >> 3) & 0x30)));
-                }
-            }
+            for (int i = 0; i < 4; ++i) y[i] = *reinterpret_cast<const f16x8*>(yp + i * (16 * YS));
             const char* wp = Wc + tl * (C * ROWB) + preW[ks];
 #pragma unroll
             for (int j = 0; j < TN; ++j) w[j] = *reinterpret_cast<const f16x8*>(wp + j * (16 * ROWB));

@@ -24,7 +24,8 @@
 // written to LDS with 8-byte stores and the output image with 16-byte stores, no shuffles.
 //
 // LDS images are unpadded; 16-byte chunk c of row r lives at chunk c ^ f(r) (swz16 below).  The XOR costs one VALU op per
-// fragment read: pre = row base | ((f(r) ^ k group) << 4) per (fragment row, tap), then address = pre ^ (k-step * 64).
+// k-step and operand: pre = row base | ((f(r) ^ k group) << 4) of row / channel tile 0 per tap, address = pre ^ (k-step * 64),
+// and tiles 1-3 (16 rows apart: same f) at immediate offsets of the same address register.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -161,12 +162,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
         const int which = tid / (C / 4), c4 = (tid % (C / 4)) * 4;
         *reinterpret_cast<f32x4*>(Bs + which * C + c4) = *reinterpret_cast<const f32x4*>((which ? p.b2 : p.b1) + c4);
     }
-    int preW[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = wn0 + 16 * j + r16;
-        preW[j] = n * ROWBW + (swz16<ROWBW>(n) ^ (kg << 4));
-    }
+    // channel tile j of a slab is 16 j rows further: 16 rows keep the swizzle term, so the four fragments of a k-step share one
+    // address and differ in the instruction's immediate offset (the VALU shares the SIMD's issue port with the MFMAs)
+    const int preW = (wn0 + r16) * ROWBW + (swz16<ROWBW>(wn0 + r16) ^ (kg << 4));
     issueW(0);
     issueY(blockIdx.x);
     RPW_TL_DECL
@@ -212,17 +210,15 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
     // ahead of it.  `hook(ks)` runs behind the MFMAs of k-step ks: the weight-slab stores and the next slab's loads are
     // spread over the k-steps there instead of forming a 32 KB ds_write burst at the slab boundary.
     auto compute = [&](int roff, int cb16, const char* Wc, auto&& hook) {
-        int preY[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = wm0 + 16 * i + r16 + roff;
-            preY[i] = r * ROWBY + (swz16<ROWBY>(r) ^ (kg << 4));
-        }
+        const int r0 = wm0 + r16 + roff;                               // row tile i: 16 i rows further, same swizzle term
+        const int preY = r0 * ROWBY + (swz16<ROWBY>(r0) ^ (kg << 4));
         auto load = [&](f16x8 (&y)[4], f16x8 (&w)[4], int ks) {
+            const char* yp = Ys + (preY ^ (cb16 + ks * 64));
+            const char* wp = Wc + (preW ^ (ks * 64));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) y[i] = *reinterpret_cast<const f16x8*>(Ys + (preY[i] ^ (cb16 + ks * 64)));
+            for (int i = 0; i < 4; ++i) y[i] = *reinterpret_cast<const f16x8*>(yp + i * (16 * ROWBY));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const f16x8*>(Wc + (preW[j] ^ (ks * 64)));
+            for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const f16x8*>(wp + j * (16 * ROWBW));
         };
         auto mma = [&](const f16x8 (&y)[4], const f16x8 (&w)[4]) {
 #pragma unroll

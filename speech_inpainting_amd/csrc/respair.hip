@@ -358,6 +358,7 @@ int si_launch_respair(si_ctx* ctx, int C, const unsigned short* y16, unsigned sh
     // C = 32: every tap of a convolution in one slab (11 x 2 KB), 256 rows, two 4-wave workgroups per CU
     // C = 64: 4 taps per slab (32 KB), 512 rows, one 8-wave workgroup per CU
     // (C = 64 as two 4-wave workgroups per CU on 256 rows with 2-tap slabs, same-box A/B: 153 / 235 / 317 us per launch for
-    // k = 3 / 7 / 11 against 160 / 231 / 293 -- kept on 512 rows)
+    // k = 3 / 7 / 11 against 160 / 231 / 293 -- kept on 512 rows; again after the tap loop lost its address arithmetic:
+    // 190 us per launch over the family against 178)
     return C == 32 ? respair_launch<32, 256, 4, 11>(ctx, p, st) : respair_launch<64, 512, 8, 4>(ctx, p, st);
 }

@@ -6,7 +6,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int READS, int PAIRLOOP, int STAGGER = 0, int PRIO = 0, int NY = 6, int NW = 2>
+// ADDR 1: one swizzled address per tap, the row tiles at immediate offsets (round 3); AGPR 1: accumulators pinned to AccVGPRs
+template <int READS, int PAIRLOOP, int STAGGER = 0, int PRIO = 0, int NY = 6, int NW = 2, int ADDR = 0, int AGPR = 0>
 __global__ __launch_bounds__(512, 1) void k(float* out, const _Float16* src, int rounds, int kt, int dd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -26,6 +27,16 @@ __global__ __launch_bounds__(512, 1) void k(float* out, const _Float16* src, int
         auto load = [&](f16x8 (&y)[NY], f16x8 (&w)[NW], int tap) {
             if (!READS && tap > 0) return;
             const int soff = (tap - c) * dd * 64;
+            if constexpr (ADDR) {
+                const int lin = lin0[0] + soff;
+                const char* ap = As + (lin ^ ((lin >> 3) & 32));
+                const char* wp = Wc + tap * (NW * 1024) + preW[0];
+#pragma unroll
+                for (int i = 0; i < NY; ++i) y[i] = *reinterpret_cast<const f16x8*>(ap + i * 1024);
+#pragma unroll
+                for (int j = 0; j < NW; ++j) w[j] = *reinterpret_cast<const f16x8*>(wp + j * 1024);
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < NY; ++i) { const int lin = lin0[i] + soff; y[i] = *reinterpret_cast<const f16x8*>(As + (lin ^ ((lin >> 3) & 32))); }
 #pragma unroll
@@ -35,7 +46,10 @@ __global__ __launch_bounds__(512, 1) void k(float* out, const _Float16* src, int
 #pragma unroll
             for (int i = 0; i < NY; ++i)
 #pragma unroll
-                for (int j = 0; j < NW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], y[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NW; ++j) {
+                    if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(w[j]), "v"(y[i]));
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], y[i], acc[i][j], 0, 0, 0);
+                }
         };
         f16x8 ya[NY], wa[NW], yb[NY], wb[NW];
         load(ya, wa, 0);
@@ -101,6 +115,9 @@ int main() {
         run(k<1, 1, 0, 1>, "6 x 2, LDS reads, setprio 1 on MFMA blocks", kt, 1);
         run(k<1, 1, 2, 0>, "6 x 2, LDS reads, second half sleeps 128", kt, 1);
         run(k<1, 0>, "6 x 2, LDS reads, one fragment set", kt, 1);
+        run(k<1, 1, 0, 0, 6, 2, 1>, "6 x 2, LDS reads, shared address", kt, 1);
+        run(k<1, 1, 0, 0, 6, 2, 1, 1>, "6 x 2, LDS reads, shared address, AGPR acc", kt, 1);
+        run(k<0, 1, 0, 0, 6, 2, 1, 1>, "6 x 2, no reads, AGPR acc", kt, 1);
     }
     // the 64 x 64 wave tile of the wide kernels / lingemm: 4 + 4 fragment reads per 16 MFMAs (the read addresses move with
     // the step, so the compiler cannot hoist them as it can in mfma_rate.hip's LDS-fed mode)
@@ -108,6 +125,9 @@ int main() {
         run(k<0, 1, 0, 0, 4, 4>, "4 x 4 fragments, no LDS reads after step 0", kt, 1, 16);
         run(k<1, 1, 0, 0, 4, 4>, "4 x 4 fragments, LDS reads (8 per 16 MFMAs)", kt, 1, 16);
         run(k<1, 1, 0, 1, 4, 4>, "4 x 4, LDS reads, setprio 1 on MFMA blocks", kt, 1, 16);
+        run(k<1, 1, 0, 0, 4, 4, 1>, "4 x 4, LDS reads, shared address", kt, 1, 16);
+        run(k<1, 1, 0, 0, 4, 4, 1, 1>, "4 x 4, LDS reads, shared address, AGPR acc", kt, 1, 16);
+        run(k<0, 1, 0, 0, 4, 4, 1, 1>, "4 x 4, no reads, AGPR acc", kt, 1, 16);
     }
     return 0;
 }

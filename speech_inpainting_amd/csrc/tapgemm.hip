@@ -669,7 +669,7 @@ static int launch_cfg(si_ctx* ctx, const TapGemmParams& p, hipStream_t st) {
     pk.wide_epilogue = wide;
     if ((p.res16 || p.acc16) && MATH != SI_MATH_BF16 && MATH != SI_MATH_F16)
         return si_fail(ctx, SI_EINVAL, "tapgemm: 16-bit residual / accumulate exist in the bf16 and fp16 math modes only");
-    si_prof_begin(ctx, name, 2.0 * macs, bytes, st);
+    si_prof_begin(ctx, si_prof_shape_name(name, p.M * (long)p.nseg, p.N * p.groups, p.Cin * p.ntaps), 2.0 * macs, bytes, st);   // (per shape under SI_PROF_SHAPES=1)
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, pk);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());

@@ -5,13 +5,16 @@
 //   PRE 1   the first fragments of slab s + 1 are read BEFORE the barrier that ends slab s (the slab must then have been
 //           published one barrier earlier: a deeper weight ring)
 //   WST 1   every wave also stores 4 x 16 bytes per lane per slab into the other weight buffer (the staging stores)
+//   GRP 1   no workgroup barrier per slab: the waves form two groups of four (one wave of each group per SIMD: waves 0-3 own
+//           channel half 0, waves 4-7 half 1) that meet at a counter in LDS (one ds_add per wave, then polling) -- the two
+//           waves of a SIMD drift apart instead of being re-aligned every slab
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int KS, int PRE, int WST>
+template <int KS, int PRE, int WST, int GRP = 0>
 __global__ __launch_bounds__(512, 1) void k(float* out, const _Float16* src, int rounds, int nslab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -20,7 +23,11 @@ __global__ __launch_bounds__(512, 1) void k(float* out, const _Float16* src, int
     __syncthreads();
     const char* Ys = smem;                                             // 306 rows x 256 bytes
     char* Ws = smem + 80 * 1024;                                       // 2 x 32 KB
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int wm0 = GRP ? (wave & 3) * 64 : (wave >> 1) * 64, wn0 = GRP ? (wave >> 2) * 64 : (wave & 1) * 64;
+    unsigned* const cnt = reinterpret_cast<unsigned*>(smem + 144 * 1024 - 64) + (wave >> 2) * 4;   // one counter per group
+    if (tid < 16) reinterpret_cast<unsigned*>(smem + 144 * 1024 - 64)[tid] = 0;
+    __syncthreads();
+    unsigned epoch = 0;
     const int preW = (wn0 + r16) * 256 + ((((wn0 + r16) & 7) << 5) ^ (kg << 4));
     f32x4 acc[4][4];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 1.f, 2.f};
@@ -68,7 +75,13 @@ __global__ __launch_bounds__(512, 1) void k(float* out, const _Float16* src, int
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();
+            if constexpr (GRP) {
+                epoch += 4;
+                __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): this wave's LDS reads / stores are done
+                if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - epoch)) < 0)
+                    __builtin_amdgcn_s_sleep(1);
+            } else __syncthreads();
         }
     }
     float sres = 0.f;
@@ -105,6 +118,9 @@ int main() {
     run(k<2, 0, 0>, "2 k-steps per slab, first reads after the barrier", 2, 28);
     run(k<2, 1, 0>, "2 k-steps per slab, first reads before the barrier", 2, 28);
     run(k<2, 1, 1>, "2 k-steps per slab, reads before, staging stores", 2, 28);
+    run(k<4, 0, 0, 1>, "4 k-steps per slab, reads after, two 4-wave groups at LDS counters", 4, 14);
+    run(k<4, 1, 0, 1>, "4 k-steps per slab, reads before, two 4-wave groups at LDS counters", 4, 14);
+    run(k<2, 0, 0, 1>, "2 k-steps per slab, reads after, two 4-wave groups at LDS counters", 2, 28);
     run(k<8, 0, 0>, "8 k-steps per slab, first reads after the barrier", 8, 7);
     run(k<8, 1, 0>, "8 k-steps per slab, first reads before the barrier", 8, 7);
     return 0;

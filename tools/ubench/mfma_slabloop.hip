@@ -5,6 +5,9 @@
 //   PRE 1   the first fragments of slab s + 1 are read BEFORE the barrier that ends slab s (the slab must then have been
 //           published one barrier earlier: a deeper weight ring)
 //   WST 1   every wave also stores 4 x 16 bytes per lane per slab into the other weight buffer (the staging stores)
+//   WST 2   the real thing: slab s + 2 is requested from global memory (an L2-resident weight array, 7 x 32 KB) slot by slot
+//           behind the MFMA blocks while slab s + 1 leaves its registers for LDS (respair_wide.hip's hook)
+//   WST 3   the same traffic as LDS-DMA (buffer_load ... lds, no registers, no ds_write), waited for before the barrier
 //   GRP 1   no workgroup barrier per slab: the waves form two groups of four (one wave of each group per SIMD: waves 0-3 own
 //           channel half 0, waves 4-7 half 1) that meet at a counter in LDS (one ds_add per wave, then polling) -- the two
 //           waves of a SIMD drift apart instead of being re-aligned every slab
@@ -49,6 +52,13 @@ __global__ __launch_bounds__(512, 1) void k(float* out, const _Float16* src, int
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[j], y[i], acc[i][j], 0, 0, 0);
     };
     const f32x4 stv = {1.f, 2.f, 3.f, 4.f};
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(src), 0, 7 * 32768, 0x00020000);
+    u32x4 rw[4];
+    if constexpr (WST == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (i * 512 + tid) * 16, 0, 0);
+    }
     for (int r = 0; r < rounds; ++r) {
         if (PRE) load(ya, wa, 0, 0);
         for (int s = 0; s < nslab; ++s) {
@@ -61,7 +71,24 @@ __global__ __launch_bounds__(512, 1) void k(float* out, const _Float16* src, int
                 mma(ya, wa);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (WST) {
+                if constexpr (WST == 2) {
+                    constexpr int SPI = 8 / KS > 0 ? 8 / KS : 1;
+                    const int soff = __builtin_amdgcn_readfirstlane(((s + 2) % 7) * 32768);
+#pragma unroll
+                    for (int q = 0; q < SPI; ++q) {
+                        const int i = (ks / 2 * SPI + q) & 3;
+                        *reinterpret_cast<u32x4*>(Ws + ((s + 1) & 1) * 32768 + (i * 512 + tid) * 16) = rw[i];
+                        rw[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (i * 512 + tid) * 16, soff, 0);
+                    }
+                } else if constexpr (WST == 3) {
+                    constexpr int SPI = 8 / KS > 0 ? 8 / KS : 1;
+                    const int soff = __builtin_amdgcn_readfirstlane(((s + 1) % 7) * 32768);
+#pragma unroll
+                    for (int q = 0; q < SPI; ++q) {
+                        const int i = (ks / 2 * SPI + q) & 3;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(Ws + ((s + 1) & 1) * 32768 + (i * 512 + wave * 64) * 16), 16, lane * 16 + (i * 512 + wave * 64) * 16, soff, 0, 0);
+                    }
+                } else if (WST) {
                     constexpr int SPI = 8 / KS > 0 ? 8 / KS : 1;           // stores per loop trip: 4 per slab
 #pragma unroll
                     for (int q = 0; q < SPI; ++q)
@@ -81,7 +108,10 @@ __global__ __launch_bounds__(512, 1) void k(float* out, const _Float16* src, int
                 if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 while (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - epoch)) < 0)
                     __builtin_amdgcn_s_sleep(1);
-            } else __syncthreads();
+            } else {
+                if constexpr (WST == 3) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+                __syncthreads();
+            }
         }
     }
     float sres = 0.f;
@@ -92,7 +122,7 @@ __global__ __launch_bounds__(512, 1) void k(float* out, const _Float16* src, int
 int main() {
     int ncu = 0;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
-    std::vector<_Float16> h(8192);
+    std::vector<_Float16> h(7 * 16384);
     unsigned x = 12345;
     for (auto& e : h) { x = x * 1664525u + 1013904223u; e = (_Float16)(((x >> 8) & 0xffff) / 65536.0f - 0.5f); }
     _Float16* src; float* out;
@@ -115,6 +145,9 @@ int main() {
     run(k<4, 1, 0>, "4 k-steps per slab, first reads before the barrier", 4, 14);
     run(k<4, 0, 1>, "4 k-steps per slab, reads after, staging stores", 4, 14);
     run(k<4, 1, 1>, "4 k-steps per slab, reads before, staging stores", 4, 14);
+    run(k<4, 0, 2>, "4 k-steps per slab, reads after, slabs staged from L2 through registers", 4, 14);
+    run(k<4, 1, 2>, "4 k-steps per slab, reads before, slabs staged from L2 through registers", 4, 14);
+    run(k<4, 0, 3>, "4 k-steps per slab, reads after, slabs staged from L2 by LDS-DMA", 4, 14);
     run(k<2, 0, 0>, "2 k-steps per slab, first reads after the barrier", 2, 28);
     run(k<2, 1, 0>, "2 k-steps per slab, first reads before the barrier", 2, 28);
     run(k<2, 1, 1>, "2 k-steps per slab, reads before, staging stores", 2, 28);

@@ -762,12 +762,142 @@ __global__ __launch_bounds__(256) void attention_bf16in_kernel(const unsigned sh
     }
 }
 
+// T <= 256 (every 4 s clip: T = 199): ONE workgroup per (clip, head) with one wave per 32 queries and the clip's WHOLE K and V
+// staged once -- one barrier per launch instead of two per key tile, K / V fetched once per (clip, head) instead of once per
+// 128 queries, and no query block that is mostly padding (T = 199 as 128 + 71).  Per key tile the arithmetic is the tiled
+// kernel's, statement for statement: bit-identical output.  LDS: per key tile a [32][ATB_LDK] block of K and a [64][ATB_LDV]
+// block of V^T (the tiled kernel's layouts): 9 216 bytes per tile, 64.5 KB at T = 199 -- two workgroups per CU.
+__global__ __launch_bounds__(512) void attention_bf16in_whole_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out16, int T,
+                                                                     int H, int heads, const int32_t* __restrict__ valid_frames) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short att_smem[];
+    const int nkt = (int)(blockDim.x >> 6);                            // key tiles == waves == ceil(T / 32)
+    unsigned short* const Ks = att_smem;                               // [nkt][32][ATB_LDK]
+    unsigned short* const Vt = att_smem + nkt * ATT_KT * ATB_LDK;      // [nkt][64][ATB_LDV]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+    const int q0 = wave * 32;
+    const long ld = 3L * H;
+    const unsigned short* base = qkv + (long)b * T * ld + h * 64;
+    const int Tk = valid_frames ? min(max(valid_frames[b], 1), T) : T;
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+    // ---- K and V of the clip -> LDS: nkt * 256 slots (one 16-byte chunk of K and one key pair x four dims of V each) over
+    //      64 * nkt threads: four slots per thread, all loads in flight before the first store
+    u32x4_t kv[4];
+    u32x2_t w0[4], w1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = tid + i * (int)blockDim.x;
+        const int k0 = (s >> 8) * ATT_KT, in = s & 255;
+        const int kr = in >> 3, kj = in & 7, vrp = in >> 4, vj = in & 15;
+        kv[i] = *reinterpret_cast<const u32x4_t*>(base + (long)min(k0 + kr, T - 1) * ld + H + 8 * kj);
+        w0[i] = *reinterpret_cast<const u32x2_t*>(base + (long)min(k0 + 2 * vrp, T - 1) * ld + 2 * H + 4 * vj);
+        w1[i] = *reinterpret_cast<const u32x2_t*>(base + (long)min(k0 + 2 * vrp + 1, T - 1) * ld + 2 * H + 4 * vj);
+    }
+    bf16x8 qb[4];
+    {
+        const int qrow = min(q0 + l31, T - 1);
+        const unsigned short* qp = base + (long)qrow * ld;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 t = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4_t*>(qp + 16 * ks + 8 * half));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qb[ks][e] = (__bf16)((float)t[e] * 0.125f);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = tid + i * (int)blockDim.x;
+        const int kt = s >> 8, k0 = kt * ATT_KT, in = s & 255;
+        const int kr = in >> 3, kj = in & 7, vrp = in >> 4, vj = in & 15;
+        *reinterpret_cast<u32x4_t*>(Ks + (kt * ATT_KT + kr) * ATB_LDK + 8 * kj) = kv[i];
+        const bool in0 = k0 + 2 * vrp < T, in1 = k0 + 2 * vrp + 1 < T;         // zero, not a clamped copy (see the tiled kernel)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned lo = in0 ? (w0[i][e >> 1] >> (16 * (e & 1))) & 0xffffu : 0u, hi = in1 ? (w1[i][e >> 1] >> (16 * (e & 1))) & 0xffffu : 0u;
+            *reinterpret_cast<unsigned*>(Vt + (kt * 64 + 4 * vj + e) * ATB_LDV + 2 * vrp) = lo | (hi << 16);
+        }
+    }
+    __syncthreads();
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float mrun = -INFINITY, lrun = 0.f;
+    for (int k0 = 0; k0 < Tk; k0 += ATT_KT) {
+        const unsigned short* Kt = Ks + k0 * ATB_LDK;
+        const unsigned short* Vtt = Vt + (k0 / ATT_KT) * 64 * ATB_LDV;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(Kt + l31 * ATB_LDK + 16 * ks + 8 * half);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qb[ks], s, 0, 0, 0);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (key >= Tk) s[r] = -INFINITY;
+            tmax = fmaxf(tmax, s[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mrun, tmax);
+        const float alpha = __expf(mrun - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - mnew); psum += s[r]; }
+        psum += __shfl_xor(psum, 32, 64);
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 pb;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pb[i] = (__bf16)s[8 * st + i];
+            const unsigned short* v0p = Vtt + l31 * ATB_LDV + 16 * st + 4 * half;
+            const unsigned short* v1p = Vtt + (32 + l31) * ATB_LDV + 16 * st + 4 * half;
+            bf16x8 va, vc;
+            const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(v0p), a1 = *reinterpret_cast<const bf16x4*>(v0p + 8);
+            const bf16x4 c0 = *reinterpret_cast<const bf16x4*>(v1p), c1 = *reinterpret_cast<const bf16x4*>(v1p + 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { va[e] = a0[e]; va[4 + e] = a1[e]; vc[e] = c0[e]; vc[4 + e] = c1[e]; }
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc, pb, o1, 0, 0, 0);
+        }
+    }
+    const int q = q0 + l31;
+    if (q < T) {
+        const float inv = 1.0f / lrun;
+        const long o = ((long)b * T + q) * H + h * 64;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = 8 * g4 + 4 * half;
+            f32x4 a = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
+            f32x4 c = {o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv};
+            *reinterpret_cast<bf16x4*>(out16 + o + d) = __builtin_convertvector(a, bf16x4);
+            *reinterpret_cast<bf16x4*>(out16 + o + 32 + d) = __builtin_convertvector(c, bf16x4);
+        }
+    }
+}
+
 int si_launch_attention_bf16in(si_ctx* ctx, const unsigned short* qkv16, int B, int T, int H, int heads, hipStream_t st, unsigned short* out16,
                                const int32_t* valid_frames) {
     if (heads <= 0 || H != heads * 64) return si_fail(ctx, SI_EINVAL, "attention kernel needs head_dim 64 (H=%d heads=%d)", H, heads);
     if (B <= 0 || T <= 0) return SI_OK;
     dim3 grid((T + 127) / 128, B * heads);
     si_prof_begin(ctx, "attention_bf16", 4.0 * B * (double)T * T * H, 8.0 * B * T * H, st);
+    if (T <= 256) {                                                    // the whole clip's K / V in LDS, one workgroup per (clip, head)
+        const int nkt = (T + ATT_KT - 1) / ATT_KT;
+        const size_t lds = (size_t)nkt * (ATT_KT * ATB_LDK + 64 * ATB_LDV) * sizeof(unsigned short);
+        if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(attention_bf16in_whole_kernel), lds)) return rc;
+        hipLaunchKernelGGL(attention_bf16in_whole_kernel, dim3(B * heads), dim3(64 * nkt), lds, st, qkv16, out16, T, H, heads, valid_frames);
+    } else
     hipLaunchKernelGGL(attention_bf16in_kernel, grid, dim3(256), 0, st, qkv16, out16, T, H, heads, valid_frames);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());

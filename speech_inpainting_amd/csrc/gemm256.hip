@@ -333,7 +333,6 @@ int si_launch_gemm256(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     const int nk = p.K / G_BK;
     const int cus = si_num_cus(ctx);
     q.persistent = (nk % 6 == 0 && run_max * 8 > cus) ? 1 : 0;
-    if (getenv("SI_G256_PERSIST")) q.persistent = q.persistent && atoi(getenv("SI_G256_PERSIST")) != 0;      // experiment
     const unsigned grid = (unsigned)(q.persistent ? std::min(run_max, cus / 8) * 8 : run_max * 8);
     const double macs = (double)p.nseg * p.M * p.N * (double)p.K;
     const double outs = (double)p.nseg * p.M * p.N;

@@ -177,8 +177,10 @@ __global__ void conv0_bias_affine_kernel(int B, int C, const float* __restrict__
 }
 
 // out[b][t][c] = act(a[b][c] * sum_k w[c][k] * xhat[b][s*t+k] + sh[b][c]); channels-last, written once.
+// FAST (the bf16-only output of the bf16 encoder mode): erf by the GEMM epilogues' 15-operation form (si_gelu_fast, |error| <= 1.5e-7
+// before the value is rounded to 8 bits): 152 -> 140 us for 32 clips.
 #define SI_C0_ROWS 64
-template <int K, bool GELU>
+template <int K, bool GELU, bool FAST = false>
 __global__ __launch_bounds__(256) void conv0_apply_kernel(WaveNormParams p, const double* __restrict__ stats,
                                                           const float* __restrict__ w, const float* __restrict__ affine,
                                                           float* __restrict__ out, unsigned short* __restrict__ out16) {
@@ -223,9 +225,11 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(WaveNormParams p, cons
 #pragma unroll
             for (int k = 0; k < K; ++k) acc = fmaf(wr[e][k], xv[k], acc);
             float v = fmaf(av[e], acc, sv[e]);
-            y[e] = GELU ? gelu_erf(v) : v;
+            y[e] = GELU ? (FAST ? si_gelu_fast(v) : gelu_erf(v)) : v;
         }
         // out16: the only consumer is a bf16 GEMM-form conv -- write its operand (half the 26 MB/clip) instead of fp32
+        // (16-byte stores of eight channels per thread, and the taps and the erf on packed fp32 operations: the same 140 us --
+        //  the kernel runs at the rate of its 419 MB of stores, 2.9 TB/s)
         if (out16) *reinterpret_cast<bf16x4*>(out16 + ((long)b * p.L1 + t0 + r) * C + c4) = __builtin_convertvector(y, bf16x4);
         else *reinterpret_cast<f32x4*>(out + ((long)b * p.L1 + t0 + r) * C + c4) = y;
     }
@@ -258,7 +262,8 @@ static int conv0_apply(si_ctx* ctx, const WaveNormParams& p, const double* stats
     dim3 grid((p.L1 + SI_C0_ROWS - 1) / SI_C0_ROWS, p.B);
     const size_t lds = ((size_t)(SI_C0_ROWS - 1) * p.S + p.K) * sizeof(float);
     si_prof_begin(ctx, "conv0_apply", 2.0 * p.B * p.L1 * (double)p.C * p.K, p.B * (4.0 * p.N + (out16 ? 2.0 : 4.0) * p.L1 * p.C), st);
-    if (gelu) hipLaunchKernelGGL((conv0_apply_kernel<10, true>), grid, dim3(256), lds, st, p, stats, w, affine, out, out16);
+    if (gelu && out16) hipLaunchKernelGGL((conv0_apply_kernel<10, true, true>), grid, dim3(256), lds, st, p, stats, w, affine, out, out16);
+    else if (gelu) hipLaunchKernelGGL((conv0_apply_kernel<10, true>), grid, dim3(256), lds, st, p, stats, w, affine, out, out16);
     else hipLaunchKernelGGL((conv0_apply_kernel<10, false>), grid, dim3(256), lds, st, p, stats, w, affine, out, out16);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float t = (v[j][e] - mean) * rstd * g[e] + bt[e];
-                    o[e] = GELU ? gelu_erf(t) : t;
+                    o[e] = GELU ? (y ? gelu_erf(t) : si_gelu_fast(t)) : t;   // bf16-only output: the GEMM epilogues' erf (common.h)
                 }
                 if (y) *reinterpret_cast<f32x4*>(yr + i) = o;           // (y16 alone: the only consumer is a bf16 GEMM)
                 // operand-ready copy for a bf16 GEMM consumer (round-to-nearest-even, as the GEMM's own staging would)

@@ -4,6 +4,8 @@
 //                 transpose the generator kernels want; channel padding written as zeros.
 //  * conv_post  : leaky_relu(0.01) -> Conv1d(C -> 1, k=7, pad 3) -> tanh (I_ea/hifi_gan/models.py:119-121),
 //                 the tail of the generator: 1 output channel, so it is a per-sample dot product, not a GEMM.
+#include <algorithm>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -96,10 +98,87 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     wav[(long)b * L + t] = tanhf(acc);
 }
 
+// The same tail on the fp16 activation stream (C = 32), on the matrix pipe: out[t] = sum_tap w[tap] . y[t + tap] is an N = 1 GEMM;
+// as 16-column MFMAs with 15 zero columns it wastes 15/16 of the pipe and still takes a tenth of the time the per-lane dot
+// product spends on its LDS reads (7 x 8 ds_read_b128 of activations + as many of weights per output sample; here 7 fragment
+// reads per 16 samples, the weights in registers).  512 samples per workgroup (33 KB of LDS: four workgroups per CU overlap each
+// other's staging): the (512 + 6) x 32 rows are staged with the
+// leaky-ReLU(0.01) applied to the packed halves (max(x, 0.01 x)), 64-byte rows in reschain.hip's swizzle; orientation
+// D^T = W . Y^T: lane (time row, k group 0) holds output channel 0 in accumulator element 0.  Operands are fp16 (the mode's
+// rounding everywhere else: activations are stored that way, the 224 weights are rounded once), accumulation fp32.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+#define CPM_ROWS 512
+__global__ __launch_bounds__(256) void conv_post_mfma_kernel(const unsigned short* __restrict__ x16, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, int B, int L, float* __restrict__ wav) {
+    constexpr int C = 32, K = 7, PAD = 3, NR = CPM_ROWS + K - 1;
+    __shared__ __attribute__((aligned(16))) char ys[(NR + 2) * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    // weights of tap k as the A operand: row n = output channel (only n = 0 is real), this lane's 8 channels 8 kg ... 8 kg + 7
+    f16x8 wf[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wf[k][e] = r16 == 0 ? (_Float16)w[k * C + 8 * kg + e] : (_Float16)0.f;
+    const float b0 = bias[0];
+    // persistent workgroups: tile = (clip, 512-sample block); the rows of the NEXT tile are requested before this one is
+    // computed (all of them in flight at once: one HBM round trip per tile, hidden behind the previous tile's work)
+    const int tiles_x = (L + CPM_ROWS - 1) / CPM_ROWS, total = tiles_x * B;
+    constexpr int NSLOT = (NR * 4 + 255) / 256;
+    u32x4v raw[NSLOT];
+    auto issue = [&](int tile) {
+        const int tb = tile / tiles_x, tt0 = (tile - tb * tiles_x) * CPM_ROWS;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x16 + (long)tb * L * C), 0, L * C * 2, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int q = tid + i * 256;
+            const int t = tt0 - PAD + (q >> 2);                        // rows outside the clip read as zero through the descriptor
+            raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (t < 0 || q >= NR * 4) ? (int)0x80000000 : (t * C + 8 * (q & 3)) * 2, 0, 0);
+        }
+    };
+    issue(blockIdx.x);
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int b = tile / tiles_x, t0 = (tile - b * tiles_x) * CPM_ROWS;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int q = tid + i * 256;
+            const int r = q >> 2, ch = q & 3;
+            f16x8 h = __builtin_bit_cast(f16x8, raw[i]);
+            h = __builtin_elementwise_max(h, h * (_Float16)0.01f);    // leaky_relu, default slope (models.py:119)
+            if (q < NR * 4) *reinterpret_cast<f16x8*>(ys + r * 64 + ((ch << 4) ^ (((r >> 1) & 3) << 4))) = h;
+        }
+        __syncthreads();
+        issue(tile + (int)gridDim.x < total ? tile + (int)gridDim.x : tile);   // clamped: unconditional loads
+        // wave w: row tiles w, w + 4, ...; a tap moves the fragment by one row, so the swizzled address is formed per (tile, tap)
+        for (int rt = wave; rt < CPM_ROWS / 16; rt += 4) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int lin0 = (rt * 16 + r16) * 64 + (kg << 4);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int lin = lin0 + k * 64;
+                const f16x8 y = *reinterpret_cast<const f16x8*>(ys + (lin ^ ((lin >> 3) & 0x30)));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k], y, acc, 0, 0, 0);
+            }
+            const int t = t0 + rt * 16 + r16;
+            if (kg == 0 && t < L) wav[(long)b * L + t] = tanhf(acc[0] + b0);
+        }
+        __syncthreads();                                               // the tile is consumed: the next one may be staged
+    }
+}
+
 int si_launch_conv_post(si_ctx* ctx, const float* x, const float* w, const float* bias, int B, int L, int C, int k, float* wav,
                         hipStream_t st, const unsigned short* x16) {
     if (C % 4 != 0) return si_fail(ctx, SI_EINVAL, "conv_post: C=%d must be a multiple of 4", C);
     if (B <= 0 || L <= 0) return SI_OK;
+    if (x16 && C == 32 && k == 7 && (long)L * C * 2 < (1L << 31)) {    // the fp16 stream's tail on the matrix pipe
+        si_prof_begin(ctx, "conv_post", 2.0 * B * L * (double)C * k, (double)B * L * (2.0 * C + 4.0), st);
+        const int total = ((L + CPM_ROWS - 1) / CPM_ROWS) * B;
+        hipLaunchKernelGGL(conv_post_mfma_kernel, dim3(std::min(total, si_num_cus(ctx) * 4)), dim3(256), 0, st, x16, w, bias, B, L, wav);
+        si_prof_end(ctx, st);
+        SI_HIP_CHECK(hipGetLastError());
+        return SI_OK;
+    }
     const size_t lds = ((size_t)(256 + k - 1) * (C + 4) + (size_t)k * C) * sizeof(float);
     if (lds > 160 * 1024) return si_fail(ctx, SI_EINVAL, "conv_post: %d channels x %d taps need %zu bytes of LDS (> 160 KiB)", C, k, lds);
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(conv_post_kernel), lds)) return rc;

@@ -1130,7 +1130,21 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
             const long Lo = Lc * u;
             float* U = buf[2];
             // B2: leaky_relu(0.1) -> ConvTranspose1d as `u` phases of a 2-tap conv: row u' reads input rows u', u'-1, ...
-            {
+            bool ups_done = false;
+            if (r16 && (fuse_mask & 2) && u == 2 && k == 4) {          // (SI_VOC_FUSE: bit 1 = this kernel, the width bits = the ResBlock kernels)
+                // the late upsamplers (128 / 64 input channels) are HBM-bound: a persistent streaming kernel (upsample.hip)
+                const GemmW& G = Ly.ups[i];
+                UpsampleParams q{};
+                q.x16 = x16; q.w = reinterpret_cast<const unsigned short*>(ctx->wdev + G.w); q.bias = reinterpret_cast<const float*>(ctx->wdev + G.bias);
+                q.out16 = U16; q.B = Bc; q.Lin = (int)Lc; q.M = (int)((pad + Lo - 1) / u + 1); q.Cin = c; q.N = u * cout; q.taps = G.ntaps;
+                q.ooff = (long)pad * cout; q.o_clip_stride = Lo * cout; q.o_clip_elems = Lo * cout;
+                if (G.has_bias && G.Npad == G.N && G.math == SI_MATH_F16) {
+                    rc = si_launch_upsample_stream(ctx, q, st);
+                    if (rc < 0) return rc;
+                    ups_done = rc == 0;
+                }
+            }
+            if (!ups_done) {
                 TapGemmParams p = gemm_params(ctx, Ly.ups[i]);
                 p.x = x; p.out = U;
                 if (opr) { p.x = nullptr; p.x16 = x16; p.out16 = U16; p.out16_slope = r16 ? 1.f : 0.1f; }

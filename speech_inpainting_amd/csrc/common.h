@@ -212,6 +212,21 @@ __device__ __forceinline__ float si_lrelu01(float v) {
     return r;
 }
 
+// lrelu(0.1) -> ConvTranspose1d(Cin -> Cin / 2, k = 4, stride 2) of the generator's late stages on the fp16 stream, as a streaming
+// GEMM over overlapping input rows (upsample.hip): GEMM row m = input row m, columns n = phase * Cout + co, taps read rows m, m - 1.
+struct UpsampleParams {
+    const unsigned short* x16;        // (B, Lin, Cin) raw fp16
+    const unsigned short* w;          // [taps][N][Cin] fp16 (the tap-GEMM's packing)
+    const float* bias;                // [N]: the layer's bias repeated per phase
+    unsigned short* out16;            // (B, Lout, Cout) raw fp16
+    int B, Lin, M;                    // M GEMM rows per clip (Lin + 1 for k = 4, stride 2, padding 1)
+    int Cin, N, taps;
+    long ooff;                        // GEMM element (m, n) is element m * N + n - ooff of its clip's output (ooff = padding * Cout)
+    long o_clip_stride, o_clip_elems; // elements between clips / per clip of the output
+};
+// SI_OK when launched, negative on error, 1 when the shape is not covered (the caller runs the tap-GEMM)
+int si_launch_upsample_stream(si_ctx* ctx, const UpsampleParams& p, hipStream_t st);
+
 // One ResBlock1 step y' = (y + conv2(lrelu(conv1(lrelu(y)) + b1)) + b2) * alpha [+ previous y'] as one kernel on the raw
 // fp16 activation stream (respair.hip: C = 32 / 64; respair_wide.hip: C = 128 / 256).  Returns 1 when the shape is not covered.
 struct ResPairParams {

@@ -16,7 +16,8 @@ def _engine(varch, gsd, fuse, voc="fp16", chain=True):
     from speech_inpainting_amd.arch import HubertArch
     from speech_inpainting_amd.engine import InpaintingEngine
     harch = HubertArch.tiny()
-    want = {"SI_VOC_FUSE": "1" if fuse else "0", "SI_VOC_CHAIN": "1" if chain else "0"}   # read when the context is created
+    fuse = fuse if isinstance(fuse, str) else ("1" if fuse else "0")   # a string: SI_VOC_FUSE as a mask
+    want = {"SI_VOC_FUSE": fuse, "SI_VOC_CHAIN": "1" if chain else "0"}   # read when the context is created
     old = {k: os.environ.get(k) for k in want}
     os.environ.update(want)
     try:
@@ -47,6 +48,35 @@ def test_resblock_chain_kernel_is_bit_identical_to_the_pair_kernels(B, Tm):
     d = (chain - pairs).abs().max().item()
     print(f"B={B} Tm={Tm}: max |chain - pairs| = {d:.3e}, signal rms {rms(pairs):.3f}")
     assert torch.equal(chain, pairs)
+
+
+@pytest.mark.parametrize("B,Tm", [(3, 57), (1, 1), (2, 130), (5, 3)])
+def test_streaming_upsamplers_match_the_tap_gemm_form_and_oracle(B, Tm):
+    """upsample.hip (the 128- and 64-channel transposed convolutions as persistent streaming GEMMs) against the tap-GEMM on the
+    same fp16 operands and against the fp32 oracle: SI_VOC_FUSE=480 keeps every ResBlock kernel (mask bits 32 | 64 | 128 |
+    256) and clears bit 1, the streaming upsamplers.  The two forms sum the same products in fp32 in a different order and
+    round to fp16 once; a rounding that flips is amplified by the layers behind it until the outputs are about as far apart
+    as either is from fp32 (the same bound as for the fused ResBlock kernels below).  Clips of many tiles (130 frames: 22 /
+    44 tiles per clip), ragged last tiles, one-frame clips (shorter than a tile), batches that leave workgroups with
+    different tile counts; and the clamp at +-65504 must act the same."""
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import VocoderArch
+    varch = VocoderArch.v1()
+    gsd = synth.synth_generator_state(varch)
+    mel = synth.synth_mel(B, Tm, 80, 81)
+    ref = R.generator_forward(gsd, varch, mel)[:, 0, :]
+    new = _engine(varch, gsd, True).vocode(mel.cuda(), stretch=False).cpu()
+    old = _engine(varch, gsd, "480").vocode(mel.cuda(), stretch=False).cpu()
+    assert new.shape == old.shape == ref.shape == (B, Tm * 256) and bool(torch.isfinite(new).all())
+    e_n, e_o, e_no = rms(new, ref), rms(old, ref), rms(new, old)
+    print(f"B={B} Tm={Tm}: signal rms {rms(ref):.3f}; streaming upsamplers vs oracle {e_n:.3e}, tap-GEMM form vs oracle {e_o:.3e}, one vs the other {e_no:.3e}")
+    assert e_n <= 2e-4 and e_o <= 2e-4 and e_no <= 2e-4
+    assert e_n <= 1.5 * e_o + 1e-5                                                    # no worse than the form it replaces
+    hot = synth.synth_mel(2, 9, 80, 79) * 3.0e4                                       # drives the stream into fp16 overflow
+    a = _engine(varch, gsd, True).vocode(hot.cuda(), stretch=False).cpu()
+    c = _engine(varch, gsd, "480").vocode(hot.cuda(), stretch=False).cpu()
+    assert bool(torch.isfinite(a).all()) and ((a > 0) == (c > 0)).float().mean().item() > 0.9
 
 
 def test_resblock_chain_kernel_saturates_like_the_pair_kernels():

@@ -335,7 +335,7 @@ int si_launch_zero_padded_rows(si_ctx* ctx, float* x, int B, int T, int H, const
 // persistent: wave w walks rows w, w + W, ... and requests its next row before it reduces the current one, so the reads
 // of one row overlap the two reductions and the stores of the previous one (one row per wave and launch had every wave
 // of the chip load, then reduce, then store in step: 16 us for 49 MB).
-template <bool GELU>
+template <bool GELU, int NS>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ y, unsigned short* __restrict__ y16, long rows, int C,
@@ -344,12 +344,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const long nwaves = (long)gridDim.x * 4;
     long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    f32x4 nx[8];
+    f32x4 nx[NS];
     auto fetch = [&](long r) {
         const float* xr = x + r * C;
         const float* ar = add ? add + r * C : nullptr;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NS; ++j) {
             const int i = (j * 64 + lane) * 4;
             nx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (i < C) {
@@ -360,15 +360,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     };
     fetch(row);
     for (; row < rows; row += nwaves) {
-        f32x4 v[8];
+        f32x4 v[NS];
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { v[j] = nx[j]; s += v[j][0] + v[j][1] + v[j][2] + v[j][3]; }
+        for (int j = 0; j < NS; ++j) { v[j] = nx[j]; s += v[j][0] + v[j][1] + v[j][2] + v[j][3]; }
         if (row + nwaves < rows) fetch(row + nwaves);
         const float mean = wave_sum(s) / C;
         float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NS; ++j) {
             const int i = (j * 64 + lane) * 4;
             if (i < C) {
 #pragma unroll
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const float rstd = rsqrtf(wave_sum(q) / C + eps);
         float* yr = y + row * C;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NS; ++j) {
             const int i = (j * 64 + lane) * 4;
             if (i < C) {
                 const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i);
@@ -403,12 +403,18 @@ int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const flo
     if (rows <= 0) return SI_OK;
     // 16 waves per CU (four 4-wave workgroups), each walking its share of the rows (same-box A/B over 8 / 16 / 32 waves
     // per CU and one row per wave: 0.40 / 0.35 / 0.36 / 0.37 ms per step)
-    constexpr int per_cu = 4;
+    // C <= 1024 (every width on the path): the row lives in 4 float4 registers per lane instead of 8 -- 56 VGPRs instead of 122, eight
+    // waves per SIMD instead of four -- and 32 waves per CU give every row of the B*T = 6368 launches its own wave: one HBM round
+    // trip for the whole launch instead of one and a half.
+    const bool narrow = C <= 1024;
+    const int per_cu = narrow ? 8 : 4;
     dim3 grid((unsigned)std::min<long>((rows + 3) / 4, (long)si_num_cus(ctx) * per_cu));
     if (!y && !y16) return si_fail(ctx, SI_EINVAL, "layernorm: no output");
     si_prof_begin(ctx, "layernorm", 8.0 * rows * C, (4.0 + (add ? 4.0 : 0.0) + (y ? 4.0 : 0.0) + (y16 ? 2.0 : 0.0)) * rows * C, st);
-    if (gelu) hipLaunchKernelGGL(layernorm_kernel<true>, grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
-    else hipLaunchKernelGGL(layernorm_kernel<false>, grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
+    if (gelu && narrow) hipLaunchKernelGGL((layernorm_kernel<true, 4>), grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
+    else if (gelu) hipLaunchKernelGGL((layernorm_kernel<true, 8>), grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
+    else if (narrow) hipLaunchKernelGGL((layernorm_kernel<false, 4>), grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<false, 8>), grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

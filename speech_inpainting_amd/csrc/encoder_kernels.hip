@@ -489,12 +489,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         }
         // mask keys beyond T, column max
         float tmax = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (key >= Tk) s[r] = -INFINITY;
-            tmax = fmaxf(tmax, s[r]);
+        if (k0 + ATT_KT > Tk) {                                        // only the last key tile has keys to mask (uniform branch: the
+#pragma unroll                                                         // compare / select per score was a third of the loop's VALU work)
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (key >= Tk) s[r] = -INFINITY;
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(mrun, tmax);              // finite: every tile holds at least key k0 < T
         const float alpha = __expf(mrun - mnew);           // exp(-inf) = 0 on the first tile
@@ -609,12 +612,15 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __rest
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qb[ks], s, 0, 0, 0);
         }
         float tmax = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (key >= Tk) s[r] = -INFINITY;
-            tmax = fmaxf(tmax, s[r]);
+        if (k0 + ATT_KT > Tk) {                                        // only the last key tile has keys to mask (uniform branch: the
+#pragma unroll                                                         // compare / select per score was a third of the loop's VALU work)
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (key >= Tk) s[r] = -INFINITY;
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(mrun, tmax);
         const float alpha = __expf(mrun - mnew);
@@ -725,12 +731,15 @@ __global__ __launch_bounds__(256) void attention_bf16in_kernel(const unsigned sh
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qb[ks], s, 0, 0, 0);
         }
         float tmax = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (key >= Tk) s[r] = -INFINITY;
-            tmax = fmaxf(tmax, s[r]);
+        if (k0 + ATT_KT > Tk) {                                        // only the last key tile has keys to mask (uniform branch: the
+#pragma unroll                                                         // compare / select per score was a third of the loop's VALU work)
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (key >= Tk) s[r] = -INFINITY;
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(mrun, tmax);
         const float alpha = __expf(mrun - mnew);
@@ -849,12 +858,15 @@ __global__ __launch_bounds__(512) void attention_bf16in_whole_kernel(const unsig
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qb[ks], s, 0, 0, 0);
         }
         float tmax = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (key >= Tk) s[r] = -INFINITY;
-            tmax = fmaxf(tmax, s[r]);
+        if (k0 + ATT_KT > Tk) {                                        // only the last key tile has keys to mask (uniform branch: the
+#pragma unroll                                                         // compare / select per score was a third of the loop's VALU work)
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (key >= Tk) s[r] = -INFINITY;
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(mrun, tmax);
         const float alpha = __expf(mrun - mnew);

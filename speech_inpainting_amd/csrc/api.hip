@@ -1268,8 +1268,14 @@ namespace {
 // constants of I_ea/dataset/mel_dump.py:11-20
 constexpr int FE_NFFT = 1024, FE_HOP = 441, FE_PAD = 312, FE_NMEL = 80, FE_SR = 22050, FE_NBIN = FE_NFFT / 2 + 1;
 constexpr double FE_FMIN = 0.0, FE_FMAX = 8000.0;
-constexpr int FE_N = 2 * FE_NBIN;                      // DFT GEMM columns: re | im
-constexpr int FE_LDSPEC = 1028;                        // spec row stride (16-byte aligned rows)
+// The real DFT as two half-size exact-fp32 GEMMs.  With s_k = x[k] + x[N - k] and d_k = x[k] - x[N - k] (k = 1 .. N/2 - 1; s_0 = x[0],
+// s_{N/2} = x[N/2]):  Re X[n] = sum_{k=0}^{N/2} s_k cos(2 pi n k / N),  Im X[n] = -sum_{k=1}^{N/2-1} d_k sin(2 pi n k / N) -- the
+// frames are written folded ([s_0 .. s_512 | 15 zeros | 0, d_1 .. d_511]) and each half meets a 513 x 528 / 513 x 512 matrix
+// instead of the whole frame a 1026 x 1024 one: half the MACs, the same products (one fp32 add per operand pair before them).
+constexpr int FE_KC = 528, FE_KS = 512;                // folded frame: cosine operands (513 padded to a multiple of 16) | sine operands
+constexpr int FE_FRAME = FE_KC + FE_KS;                // 1040 floats per folded frame
+constexpr int FE_IMOFF = 516;                          // spec row = [re(0..512) | 3 pad | im(0..512) | 3 pad]
+constexpr int FE_LDSPEC = 1032;                        // spec row stride (16-byte aligned halves)
 
 // Slaney mel scale (librosa.filters.mel defaults htk=False, norm='slaney', as called at mel_dump.py:66)
 double hz_to_mel(double f) {
@@ -1285,9 +1291,9 @@ size_t fe_round(size_t b) { return (b + 255) / 256 * 256; }
 
 int ensure_frontend(si_ctx* ctx) {
     if (ctx->fe_dev) return SI_OK;
-    const int npad = si_round_up(FE_N, si_pick_bn(FE_N));
-    ctx->fe_dft = 0;
-    ctx->fe_hann = ctx->fe_dft + fe_round((size_t)npad * FE_NFFT * 4);
+    const int npad = si_round_up(FE_NBIN, si_pick_bn(FE_NBIN));
+    ctx->fe_dft = 0;                                                   // [npad][FE_KC] cosines, then [npad][FE_KS] (minus) sines
+    ctx->fe_hann = ctx->fe_dft + fe_round((size_t)npad * FE_FRAME * 4);
     ctx->fe_basis = ctx->fe_hann + fe_round((size_t)FE_NFFT * 4);
     ctx->fe_lo = ctx->fe_basis + fe_round((size_t)FE_NBIN * FE_NMEL * 4);
     ctx->fe_hi = ctx->fe_lo + fe_round((size_t)FE_NMEL * 4);
@@ -1300,11 +1306,12 @@ int ensure_frontend(si_ctx* ctx) {
     int32_t* hi = reinterpret_cast<int32_t*>(host.data() + ctx->fe_hi);
     const double two_pi = 6.283185307179586476925286766559;
     for (int k = 0; k < FE_NFFT; ++k) hann[k] = (float)(0.5 - 0.5 * std::cos(two_pi * k / FE_NFFT));   // torch.hann_window (periodic)
+    float* dsin = dft + (size_t)npad * FE_KC;
     for (int n = 0; n < FE_NBIN; ++n)
-        for (int k = 0; k < FE_NFFT; ++k) {
+        for (int k = 0; k <= FE_NFFT / 2; ++k) {
             const double a = two_pi * ((long)n * k % FE_NFFT) / FE_NFFT;   // exact argument reduction
-            dft[(size_t)n * FE_NFFT + k] = (float)std::cos(a);
-            dft[(size_t)(FE_NBIN + n) * FE_NFFT + k] = (float)-std::sin(a);
+            dft[(size_t)n * FE_KC + k] = (float)std::cos(a);               // columns 0 .. 512 (513 .. 527 stay zero)
+            if (k >= 1 && k < FE_NFFT / 2) dsin[(size_t)n * FE_KS + k] = (float)-std::sin(a);   // columns 1 .. 511 (d_0 = 0)
         }
     // triangular filters on the Slaney scale, area-normalised
     std::vector<double> mel_f(FE_NMEL + 2);
@@ -1337,7 +1344,7 @@ int ensure_frontend(si_ctx* ctx) {
 size_t mel_ws_bytes(int B, int N22) {
     const long Tm = (N22 + 2 * FE_PAD - FE_NFFT) / FE_HOP + 1;
     if (Tm < 1) return 0;
-    return fe_round((size_t)B * 4) + fe_round((size_t)B * Tm * FE_NFFT * 4) + fe_round((size_t)B * Tm * FE_LDSPEC * 4) + 256;
+    return fe_round((size_t)B * 4) + fe_round((size_t)B * Tm * FE_FRAME * 4) + fe_round((size_t)B * Tm * FE_LDSPEC * 4) + 256;
 }
 
 }  // namespace
@@ -1368,24 +1375,27 @@ int si_mel_frontend(si_ctx* ctx, const float* wave22, const int32_t* mask_start,
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carver W{static_cast<char*>(workspace), workspace_bytes};
     float* peak = W.floats((size_t)B);
-    float* frames = W.floats((size_t)B * Tm * FE_NFFT);
+    float* frames = W.floats((size_t)B * Tm * FE_FRAME);
     float* spec = W.floats((size_t)B * Tm * FE_LDSPEC);
     if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: mel workspace carve exceeded its own estimate");
     const float* hann = reinterpret_cast<const float*>(ctx->fe_dev + ctx->fe_hann);
     if (normalize && (rc = si_launch_wave_peak(ctx, wave22, mask_start, mask_end, B, N22, peak, st))) return rc;
-    if ((rc = si_launch_mel_frames(ctx, wave22, mask_start, mask_end, peak, hann, B, N22, Tm, FE_HOP, FE_PAD, FE_NFFT, normalize, frames, st)))
+    if ((rc = si_launch_mel_frames(ctx, wave22, mask_start, mask_end, peak, hann, B, N22, Tm, FE_HOP, FE_PAD, FE_NFFT, FE_KC, normalize, frames, st)))
         return rc;
-    if ((rc = si_tap(ctx, "mel_frames", frames, (long)B * Tm * FE_NFFT, st))) return rc;
-    // STFT as one exact-fp32 GEMM: (B*Tm, 1024) x (1024, 1026)
-    TapGemmParams p{};
-    p.w = ctx->fe_dev + ctx->fe_dft; p.w_lo = nullptr; p.bias = nullptr; p.res = nullptr;
-    p.x = frames; p.out = spec;
-    p.nseg = 1; p.Lin = B * Tm; p.M = B * Tm; p.ldx = FE_NFFT; p.x_seg_stride = 0;
-    p.Cin = FE_NFFT; p.N = FE_N; p.Npad = si_round_up(FE_N, si_pick_bn(FE_N)); p.ntaps = 1; p.stride = 1; p.dil = 1; p.pad = 0; p.groups = 1;
-    p.ldo = FE_LDSPEC; p.o_seg_stride = 0; p.ooff = 0; p.olimit = (long)B * Tm * FE_LDSPEC;
-    p.pro_slope = 1.f; p.act = SI_ACT_NONE; p.alpha = 1.f; p.accumulate = 0;
-    if ((rc = si_launch_tapgemm(ctx, SI_MATH_F32, p, st))) return rc;
-    return si_launch_mel_project(ctx, spec, FE_LDSPEC, FE_NBIN, reinterpret_cast<const float*>(ctx->fe_dev + ctx->fe_basis),
+    if ((rc = si_tap(ctx, "mel_frames", frames, (long)B * Tm * FE_FRAME, st))) return rc;
+    // STFT as two exact-fp32 GEMMs on the folded frames: (B*Tm, 528) x (528, 513) -> re, (B*Tm, 512) x (512, 513) -> im
+    const int npad = si_round_up(FE_NBIN, si_pick_bn(FE_NBIN));
+    for (int half = 0; half < 2; ++half) {
+        TapGemmParams p{};
+        p.w = ctx->fe_dev + ctx->fe_dft + (half ? (size_t)npad * FE_KC * 4 : 0); p.w_lo = nullptr; p.bias = nullptr; p.res = nullptr;
+        p.x = frames + (half ? FE_KC : 0); p.out = spec + (half ? FE_IMOFF : 0);
+        p.nseg = 1; p.Lin = B * Tm; p.M = B * Tm; p.ldx = FE_FRAME; p.x_seg_stride = 0;
+        p.Cin = half ? FE_KS : FE_KC; p.N = FE_NBIN; p.Npad = npad; p.ntaps = 1; p.stride = 1; p.dil = 1; p.pad = 0; p.groups = 1;
+        p.ldo = FE_LDSPEC; p.o_seg_stride = 0; p.ooff = 0; p.olimit = (long)B * Tm * FE_LDSPEC - (half ? FE_IMOFF : 0);
+        p.pro_slope = 1.f; p.act = SI_ACT_NONE; p.alpha = 1.f; p.accumulate = 0;
+        if ((rc = si_launch_tapgemm(ctx, SI_MATH_F32, p, st))) return rc;
+    }
+    return si_launch_mel_project(ctx, spec, FE_LDSPEC, FE_NBIN, FE_IMOFF, reinterpret_cast<const float*>(ctx->fe_dev + ctx->fe_basis),
                                  reinterpret_cast<const int32_t*>(ctx->fe_dev + ctx->fe_lo),
                                  reinterpret_cast<const int32_t*>(ctx->fe_dev + ctx->fe_hi), FE_NMEL, B, Tm, mel_out, st);
 }

@@ -175,12 +175,14 @@ int si_launch_sisdr(si_ctx* ctx, const float* est, const float* ref, int B, int 
 // ------------------------------------------------------------------------------------------------
 int si_launch_wave_peak(si_ctx* ctx, const float* wav, const int32_t* ms, const int32_t* me, int B, int N, float* peak,
                         hipStream_t st);
-// mask -> normalise*0.95 -> reflect-pad -> Hann window, as the (B*Tm, nfft) frame matrix
+// mask -> normalise*0.95 -> reflect-pad -> Hann window, as the (B*Tm, kc + nfft / 2) matrix of FOLDED frames
+// [w[0], w[k] + w[nfft - k] (k = 1 .. nfft/2 - 1), w[nfft/2], zeros up to kc | 0, w[k] - w[nfft - k]]: the operands of the two
+// half-size DFT GEMMs (cosine / sine part)
 int si_launch_mel_frames(si_ctx* ctx, const float* wav, const int32_t* ms, const int32_t* me, const float* peak,
-                         const float* hann, int B, int N, int Tm, int hop, int pad, int nfft, int normalize, float* frames,
+                         const float* hann, int B, int N, int Tm, int hop, int pad, int nfft, int kc, int normalize, float* frames,
                          hipStream_t st);
-// spec rows [re | im] -> sqrt(re^2+im^2+1e-9) -> banded mel basis -> log(clamp 1e-5) -> mel (B, nmel, Tm)
-int si_launch_mel_project(si_ctx* ctx, const float* spec, int ld_spec, int nbin, const float* basis_t, const int32_t* lo,
+// spec rows [re | pad | im at im_off] -> sqrt(re^2+im^2+1e-9) -> banded mel basis -> log(clamp 1e-5) -> mel (B, nmel, Tm)
+int si_launch_mel_project(si_ctx* ctx, const float* spec, int ld_spec, int nbin, int im_off, const float* basis_t, const int32_t* lo,
                           const int32_t* hi, int nmel, int B, int Tm, float* mel, hipStream_t st);
 
 // polyphase FIR resampler (upfirdn with resample_poly's centring); taps are device fp32, already pre-padded

@@ -45,45 +45,54 @@ __global__ __launch_bounds__(1024) void wave_peak_kernel(const float* __restrict
     }
 }
 
-// grid (Tm, B), 256 threads: thread t writes samples 4t .. 4t+3 of its frame.
+// grid (Tm, B), 256 threads.  The windowed frame w[k] = x[.] * hann[k] is written FOLDED for the two half-size DFT GEMMs (api.hip):
+// [ s_0 .. s_{n/2} | zeros up to kc | 0, d_1 .. d_{n/2-1} ],  s_k = w[k] + w[n - k], d_k = w[k] - w[n - k]  (s_0 = w[0], s_{n/2} = w[n/2]).
 __global__ __launch_bounds__(256) void mel_frames_kernel(const float* __restrict__ wav, const int32_t* __restrict__ ms,
                                                          const int32_t* __restrict__ me, const float* __restrict__ peak,
                                                          const float* __restrict__ hann, int N, int Tm, int hop, int pad,
-                                                         int nfft, int normalize, float* __restrict__ frames) {
+                                                         int nfft, int kc, int normalize, float* __restrict__ frames) {
     const int m = blockIdx.x, b = blockIdx.y;
     const float* x = wav + (size_t)b * N;
     const int s = ms ? ms[b] : 0, e = ms ? me[b] : 0;
     // librosa.util.normalize: divide by max |x|; a peak below the smallest normal float leaves the clip unscaled
     const float pk = normalize ? peak[b] : 1.f;
     const float div = pk < 1.17549435e-38f ? 1.f : pk;
-    float* dst = frames + ((size_t)b * Tm + m) * nfft;
-    for (int k = threadIdx.x * 4; k < nfft; k += 1024) {
+    const int half = nfft / 2, flen = kc + half;
+    float* dst = frames + ((size_t)b * Tm + m) * flen;
+    auto win = [&](int k) {                                     // windowed sample k of this frame
+        int j = m * hop + k - pad;                              // position in the un-padded clip
+        if (j < 0) j = -j;                                      // reflect (no edge repeat), mel_dump.py:72
+        if (j >= N) j = 2 * (N - 1) - j;
+        float v = (j >= s && j < e) ? 0.f : x[j];
+        if (normalize) v = (v / div) * 0.95f;                   // predict.py:104, in the script's operation order
+        return v * hann[k];
+    };
+    for (int q = threadIdx.x * 4; q < flen; q += 1024) {
         float4 o;
         float* op = reinterpret_cast<float*>(&o);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            int j = m * hop + k + u - pad;                      // position in the un-padded clip
-            if (j < 0) j = -j;                                  // reflect (no edge repeat), mel_dump.py:72
-            if (j >= N) j = 2 * (N - 1) - j;
-            float v = (j >= s && j < e) ? 0.f : x[j];
-            if (normalize) v = (v / div) * 0.95f;               // predict.py:104, in the script's operation order
-            op[u] = v * hann[k + u];
+            const int i = q + u;
+            float v = 0.f;
+            if (i <= half) v = (i == 0 || i == half) ? win(i) : win(i) + win(nfft - i);
+            else if (i > kc) v = win(i - kc) - win(nfft - (i - kc));            // (i == kc: d_0 = 0; half < i < kc: padding)
+            op[u] = v;
         }
-        *reinterpret_cast<float4*>(dst + k) = o;
+        *reinterpret_cast<float4*>(dst + q) = o;
     }
 }
 
-// One workgroup per frame.  spec row = [re(0..nbin-1) | im(0..nbin-1)] as the DFT GEMM wrote it.
+// One workgroup per frame.  spec row = [re(0..nbin-1) | pad | im(0..nbin-1) at im_off] as the two DFT GEMMs wrote it.
 // basis_t is the mel basis transposed to (nbin, nmel); band i is non-zero on bins [lo[i], hi[i]).
 __global__ __launch_bounds__(128) void mel_project_kernel(const float* __restrict__ spec, int ld_spec, int nbin,
                                                           const float* __restrict__ basis_t, const int32_t* __restrict__ lo,
-                                                          const int32_t* __restrict__ hi, int nmel, int Tm,
+                                                          const int32_t* __restrict__ hi, int nmel, int Tm, int im_off,
                                                           float* __restrict__ mel) {
     extern __shared__ float mag[];
     const long row = blockIdx.x;
     const float* sp = spec + row * ld_spec;
     for (int f = threadIdx.x; f < nbin; f += blockDim.x) {
-        const float re = sp[f], im = sp[nbin + f];
+        const float re = sp[f], im = sp[im_off + f];
         mag[f] = sqrtf(re * re + im * im + 1e-9f);              // mel_dump.py:89
     }
     __syncthreads();
@@ -105,22 +114,22 @@ int si_launch_wave_peak(si_ctx* ctx, const float* wav, const int32_t* ms, const 
 }
 
 int si_launch_mel_frames(si_ctx* ctx, const float* wav, const int32_t* ms, const int32_t* me, const float* peak,
-                         const float* hann, int B, int N, int Tm, int hop, int pad, int nfft, int normalize, float* frames,
+                         const float* hann, int B, int N, int Tm, int hop, int pad, int nfft, int kc, int normalize, float* frames,
                          hipStream_t st) {
-    if (nfft % 4) return si_fail(ctx, SI_EINVAL, "mel_frames: n_fft %d is not a multiple of 4", nfft);
+    if (nfft % 8 || kc % 4 || kc <= nfft / 2) return si_fail(ctx, SI_EINVAL, "mel_frames: n_fft %d / folded width %d unsupported", nfft, kc);
     if (N <= pad) return si_fail(ctx, SI_EINVAL, "mel_frames: clip of %d samples is not longer than the reflect pad %d", N, pad);
     si_prof_begin(ctx, "mel_frames", 3.0 * B * Tm * nfft, (double)B * N * 4 + (double)B * Tm * nfft * 4, st);
-    mel_frames_kernel<<<dim3(Tm, B), 256, 0, st>>>(wav, ms, me, peak, hann, N, Tm, hop, pad, nfft, normalize, frames);
+    mel_frames_kernel<<<dim3(Tm, B), 256, 0, st>>>(wav, ms, me, peak, hann, N, Tm, hop, pad, nfft, kc, normalize, frames);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
 }
 
-int si_launch_mel_project(si_ctx* ctx, const float* spec, int ld_spec, int nbin, const float* basis_t, const int32_t* lo,
+int si_launch_mel_project(si_ctx* ctx, const float* spec, int ld_spec, int nbin, int im_off, const float* basis_t, const int32_t* lo,
                           const int32_t* hi, int nmel, int B, int Tm, float* mel, hipStream_t st) {
     const long rows = (long)B * Tm;
     si_prof_begin(ctx, "mel_project", (double)rows * (4.0 * nbin + 2.0 * nbin * 2), (double)rows * (2.0 * nbin + nmel) * 4, st);
-    mel_project_kernel<<<(unsigned)rows, 128, (size_t)nbin * sizeof(float), st>>>(spec, ld_spec, nbin, basis_t, lo, hi, nmel, Tm, mel);
+    mel_project_kernel<<<(unsigned)rows, 128, (size_t)nbin * sizeof(float), st>>>(spec, ld_spec, nbin, basis_t, lo, hi, nmel, Tm, im_off, mel);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

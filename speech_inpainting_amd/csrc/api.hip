@@ -180,6 +180,17 @@ struct Planner {
     }
 };
 
+// Channel count of upsampling stage i as the kernels see it.  On the fp16 activation stream a stage narrower than 32 channels
+// (I_da's unit vocoder ends on 16) is carried PADDED to 32: its weights, biases and therefore activations are zero in the extra
+// channels, and the stage runs on the 32-channel chain kernel (three launches per stage) instead of 18 tap-GEMM launches that
+// move the stream at a tenth of the HBM rate; `conv_post` reads the padded rows with zero weights.  Other modes keep the real width
+// (their per-stage taps are compared against the reference's tensors).
+int stage_channels(const si_ctx* ctx, int i) {
+    const int real = ctx->d.up_initial_channel >> (i + 1);
+    const bool r16 = ctx->opt_voc_opready && ctx->opt_voc_res16 && ctx->d.vocoder_math == SI_MATH_F16;
+    return (r16 && real < 32 && real >= 4) ? 32 : real;
+}
+
 int plan_layout(si_ctx* ctx) {
     const si_model_desc& d = ctx->d;
     Layout& L = ctx->lay;
@@ -227,9 +238,9 @@ int plan_layout(si_ctx* ctx) {
     L.ups.clear(); L.rbs.clear();
     int c = C0;
     for (int i = 0; i < d.num_ups; ++i) {
-        const int u = d.up_rates[i], k = d.up_kernels[i];
-        L.ups.push_back(P.gemm(vm, 1, (k + u - 1) / u, u * (c / 2), c, true));   // taps q = j div u; absent (phase, tap) pairs stay zero
-        c /= 2;
+        const int u = d.up_rates[i], k = d.up_kernels[i], cout = stage_channels(ctx, i);
+        L.ups.push_back(P.gemm(vm, 1, (k + u - 1) / u, u * cout, c, true));   // taps q = j div u; absent (phase, tap) pairs stay zero
+        c = cout;
         for (int j = 0; j < d.num_rb; ++j) {
             ResW r;
             for (int n = 0; n < d.num_dil; ++n) {
@@ -477,17 +488,17 @@ int pack_weights(si_ctx* ctx, Packer& P) {
     const int C0 = d.up_initial_channel;
     if (P.folded(G + "conv_pre", {C0, d.num_mels, 7}, 0, w)) P.conv(L.pre, w, C0, d.num_mels, 7);
     P.bias(L.pre, G + "conv_pre.bias", C0);
-    int c = C0;
+    int c = C0;                                            // REAL channel counts here; the packed matrices have the padded strides
     for (int i = 0; i < d.num_ups; ++i) {
-        const int u = d.up_rates[i], k = d.up_kernels[i], cout = c / 2;
+        const int u = d.up_rates[i], k = d.up_kernels[i], cout = c / 2, coutp = stage_channels(ctx, i);
         const GemmW& U = L.ups[i];
         // ConvTranspose1d weight (Cin, Cout, k), weight-norm over dim 0 (= Cin).  Phase p = j mod u, tap q = j / u.
         if (P.folded(G + "ups." + std::to_string(i), {c, cout, k}, 0, w))
             for (int ci = 0; ci < c; ++ci)
                 for (int co = 0; co < cout; ++co)
-                    for (int j = 0; j < k; ++j) P.put(U, 0, j / u, (j % u) * cout + co, ci, w[((size_t)ci * cout + co) * k + j]);
+                    for (int j = 0; j < k; ++j) P.put(U, 0, j / u, (j % u) * coutp + co, ci, w[((size_t)ci * cout + co) * k + j]);
         const HostTensor* b = P.get(G + "ups." + std::to_string(i) + ".bias", {cout});
-        if (b) for (int ph = 0; ph < u; ++ph) memcpy(P.fptr(U.bias) + (size_t)ph * cout, b->data, (size_t)cout * 4);
+        if (b) for (int ph = 0; ph < u; ++ph) memcpy(P.fptr(U.bias) + (size_t)ph * coutp, b->data, (size_t)cout * 4);
         c = cout;
         for (int j = 0; j < d.num_rb; ++j) {
             const ResW& R = L.rbs[(size_t)i * d.num_rb + j];
@@ -508,7 +519,7 @@ int pack_weights(si_ctx* ctx, Packer& P) {
         }
     }
     if (P.folded(G + "conv_post", {1, c, 7}, 0, w))
-        for (int ci = 0; ci < c; ++ci) for (int k = 0; k < 7; ++k) P.fptr(L.post_w)[(size_t)k * c + ci] = w[(size_t)ci * 7 + k];
+        for (int ci = 0; ci < c; ++ci) for (int k = 0; k < 7; ++k) P.fptr(L.post_w)[(size_t)k * L.post_C + ci] = w[(size_t)ci * 7 + k];
     P.copy_floats(L.post_b, G + "conv_post.bias", 1);
     return P.rc;
 }
@@ -559,7 +570,7 @@ size_t vocoder_ws_bytes(const si_ctx* ctx, int B, int Tm, int stretch) {
     const long Tout = voc_tout(Tm, stretch);
     size_t lc_max = (size_t)Tout * d.up_initial_channel;
     long L = Tout; int c = d.up_initial_channel;
-    for (int i = 0; i < d.num_ups; ++i) { L *= d.up_rates[i]; c /= 2; lc_max = std::max(lc_max, (size_t)L * c); }
+    for (int i = 0; i < d.num_ups; ++i) { L *= d.up_rates[i]; c = stage_channels(ctx, i); lc_max = std::max(lc_max, (size_t)L * c); }
     // 6 fp32 activation buffers + 6 half-size buffers for the operand-ready 16-bit copies (bf16 / fp16 modes)
     const size_t f = (size_t)Bc * Tout * ctx->lay.mel_ld + 9 * (size_t)Bc * lc_max;
     return f * 4 + 32 * 256;
@@ -1079,7 +1090,7 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
     size_t lc_max = (size_t)Tout * d.up_initial_channel;
     {
         long L = Tout; int c = d.up_initial_channel;
-        for (int i = 0; i < d.num_ups; ++i) { L *= d.up_rates[i]; c /= 2; lc_max = std::max(lc_max, (size_t)L * c); }
+        for (int i = 0; i < d.num_ups; ++i) { L *= d.up_rates[i]; c = stage_channels(ctx, i); lc_max = std::max(lc_max, (size_t)L * c); }
     }
     const long Lwav = si_vocoder_samples(ctx, Tm, stretch);
     Carver W{static_cast<char*>(workspace), workspace_bytes};
@@ -1126,7 +1137,7 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
         }
         long Lc = Tout; int c = d.up_initial_channel;
         for (int i = 0; i < d.num_ups; ++i) {
-            const int u = d.up_rates[i], k = d.up_kernels[i], cout = c / 2, pad = (k - u) / 2;
+            const int u = d.up_rates[i], k = d.up_kernels[i], cout = stage_channels(ctx, i), pad = (k - u) / 2;
             const long Lo = Lc * u;
             float* U = buf[2];
             // B2: leaky_relu(0.1) -> ConvTranspose1d as `u` phases of a 2-tap conv: row u' reads input rows u', u'-1, ...
@@ -1152,7 +1163,7 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                 p.nseg = Bc; p.Lin = (int)Lc; p.M = (int)((pad + Lo - 1) / u + 1); p.ldx = c; p.x_seg_stride = Lc * c;
                 p.dil = -1; p.ldo = u * cout; p.o_seg_stride = Lo * cout; p.ooff = -(long)pad * cout; p.olimit = Lo * cout;
                 p.pro_slope = (opr && !r16) ? 1.f : 0.1f;          // operand-ready inputs are already activated
-                p.algo_macs = (double)Bc * Lc * c * (double)cout * k;          // Cin*Cout*k*Lin
+                p.algo_macs = (double)Bc * Lc * (double)(d.up_initial_channel >> i) * (double)(d.up_initial_channel >> (i + 1)) * k;   // Cin*Cout*k*Lin (real widths)
                 if ((rc = si_launch_tapgemm(ctx, Ly.ups[i].math, p, st))) return rc;
             }
             if (!r16 && (rc = si_tap(ctx, upn[i], U, (long)Bc * Lo * cout, st))) return rc;

@@ -33,9 +33,12 @@ N_FFT, NUM_MELS, HOP, WIN, MEL_PAD, SR22, FMIN, FMAX = 1024, 80, 441, 1024, 312,
 def mel_filterbank(sr: int = SR22, n_fft: int = N_FFT, n_mels: int = NUM_MELS, fmin: float = FMIN, fmax: float = FMAX):
     """`librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax)` as called at I_ea/dataset/mel_dump.py:66 (htk=False,
     norm='slaney'): triangular filters on the Slaney mel scale, each scaled by 2 / (f[i+2] - f[i]).
-    librosa is absent from this image, so THIS function is pinned only by the published formula and by the
-    known-answer properties in tests/test_oracle_golden.py ("filterbank parity unpinned"); everything else in
-    `mel_spectrogram` below is the reference's own torch calls.  Returns float32 (n_mels, 1 + n_fft // 2)."""
+    librosa is absent from this image, so THIS function cannot be pinned against the reference's own dependency
+    ("filterbank parity unpinned" in that strict sense); it IS checked against an independent implementation of the same
+    filterbank -- `transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney")`, the one HuggingFace's
+    feature extractors use in librosa's place -- to 1e-9 (tests/test_oracle_golden.py), and by the known-answer
+    properties there; everything else in `mel_spectrogram` below is the reference's own torch calls.
+    Returns float32 (n_mels, 1 + n_fft // 2)."""
     import numpy as np
 
     f_sp, min_log_hz, logstep = 200.0 / 3, 1000.0, math.log(6.4) / 27.0

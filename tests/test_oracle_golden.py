@@ -255,3 +255,20 @@ def test_f0_encoder_restatement_shapes_and_known_answer():
     assert torch.allclose(out, last[None, :, None].expand_as(out))
     codes = R.f0_vq_codes(torch.randn(2, 128, 5), sd["vq.level_blocks.0.k"])
     assert codes.shape == (2, 5) and int(codes.min()) >= 0 and int(codes.max()) < 20
+
+
+def test_slaney_filterbank_matches_transformers_librosa_compatible_one():
+    """`oracle.mel_filterbank` restates `librosa.filters.mel(htk=False, norm='slaney')` (I_ea/dataset/mel_dump.py:66) from the
+    published formula; librosa is not in the image.  `transformers.audio_utils.mel_filter_bank(norm='slaney',
+    mel_scale='slaney')` is an independent implementation of the same filterbank (HuggingFace's feature extractors use it in
+    librosa's place): the two must agree to rounding, for the path's parameters and for a second set (other sample rate,
+    band count and edges)."""
+    from transformers.audio_utils import mel_filter_bank
+    for sr, n_fft, n_mels, fmin, fmax in [(22050, 1024, 80, 0.0, 8000.0), (16000, 400, 64, 50.0, 7600.0)]:
+        theirs = mel_filter_bank(num_frequency_bins=1 + n_fft // 2, num_mel_filters=n_mels, min_frequency=fmin, max_frequency=fmax,
+                                 sampling_rate=sr, norm="slaney", mel_scale="slaney")
+        ours = np.asarray(R.mel_filterbank(sr, n_fft, n_mels, fmin, fmax), dtype=np.float64)
+        assert theirs.shape == (1 + n_fft // 2, n_mels) and ours.shape == (n_mels, 1 + n_fft // 2)
+        d = np.abs(theirs.T - ours).max()
+        print(f"sr={sr} n_fft={n_fft} n_mels={n_mels}: max |ours - transformers| = {d:.3e} (filter peak {ours.max():.3e})")
+        assert d <= 1e-7 * max(ours.max(), 1e-3) + 1e-9

@@ -190,17 +190,13 @@ def roofline_of(prof, steps, table=None, table_steps=0):
 def spawn_ranks(n: int) -> int:
     """Launch `n` ranks of this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) as a
     child process; its stdout (rank 0's one JSON line) and stderr pass through.  Returns the launcher's exit code."""
-    import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this pool's host driver
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    log(f"[bench] --gpus {n} without WORLD_SIZE: launching {' '.join(cmd[1:8])} ...")
+    # --standalone: torchrun's own c10d rendezvous on a port IT binds (no bind / close / reuse race with other processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] --gpus {n} without WORLD_SIZE: launching {' '.join(cmd[1:7])} ...")
     return subprocess.run(cmd, env=env).returncode
 
 

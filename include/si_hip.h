@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SI_ABI_VERSION 2
+#define SI_ABI_VERSION 3
 
 enum {
     SI_OK = 0,
@@ -128,6 +128,11 @@ int si_load_weights(si_ctx* ctx, const void* host_blob, size_t nbytes, const cha
  * si_alloc_weights and receive its bytes by an RCCL broadcast into si_weights_device_ptr. */
 int si_alloc_weights(si_ctx* ctx);
 int si_weights_device_ptr(si_ctx* ctx, void** ptr, size_t* nbytes);
+/* The blob starts with a fingerprint of the layout it was packed for (model desc + the context's arithmetic-path options).
+ * si_weights_check compares it with THIS context's plan (one small synchronous device-to-host copy): SI_EWEIGHTS when the
+ * source rank planned a different layout or the bytes have not arrived.  Call it after the broadcast; the forwards also
+ * run it once before the first use of a blob that came from si_alloc_weights. */
+int si_weights_check(si_ctx* ctx);
 
 /* Workspace (device scratch) needed for a batch of B clips of N samples and Tm mel frames. */
 int si_workspace_bytes(si_ctx* ctx, int B, int N, int Tm, size_t* out);
@@ -151,6 +156,18 @@ int si_hubert_forward(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
 int si_hubert_forward_padded(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len,
                              const int32_t* valid_len, int normalize, int B, int N, float* out_feats, void* workspace,
                              size_t workspace_bytes, si_stream_t stream);
+
+/* RAGGED batches (BASELINE configs[4]: clips of different lengths, I_ea/config.yaml:11 "10.1 s", I_ea/mask_pos_len.py:28-35): B clips
+ * of DIFFERENT lengths in one call, each clip's result EQUAL to that clip run alone -- the reference's script handles one file of
+ * any length per invocation (I_ea/predict.py:76-207) -- and not the padded semantics of si_hubert_forward_padded (whose GroupNorm
+ * sees the padding, as HuggingFace's does).  wav (B, N): clip b occupies the first sample_len[b] samples of its row, the rest is
+ * ignored.  sample_len: HOST int32 (B) (launch grids depend on it).  mask_start / mask_len as si_hubert_forward.
+ * Per clip: the processor's statistics over its own samples, conv0's GroupNorm statistics over its own conv rows, every strided
+ * convolution stops at its own length (modeling_hubert.py:664-677), the transformer runs on the packed rows of all clips (the
+ * positional conv's zero padding begins at the clip's own last frame, attention sees its own frames only).
+ * out_feats (B, T, codebook_dim) with T = si_num_frames(N): rows >= si_num_frames(sample_len[b]) of clip b are zero. */
+int si_hubert_forward_varlen(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len, const int32_t* sample_len,
+                             int normalize, int B, int N, float* out_feats, void* workspace, size_t workspace_bytes, si_stream_t stream);
 
 /* I_da's encoder call: `HubertFeatureReader.get_feats` (I_da/src/hubert_feature_reader.py:44-67) =
  * optional `F.layer_norm(x, x.shape)` over the whole clip (:53-54, when the checkpoint's task.cfg.normalize is set) followed by
@@ -189,6 +206,11 @@ int si_code_splice(si_ctx* ctx, const int64_t* code_clean, const int64_t* code_m
  * labels device int64 (B, Lm), may be NULL. */
 int si_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, const int32_t* frame_pos, int Lm,
                        float* mel, int Tm, int64_t* labels, si_stream_t stream);
+
+/* The same with a per-clip frame COUNT (ragged batches; blind inpainting replaces all of a clip's own frames): frame_cnt device
+ * int32 (B), 0 <= frame_cnt[b] <= Lm; labels (B, Lm) get -1 past a clip's count. */
+int si_codebook_splice_varlen(si_ctx* ctx, const float* feats, int B, int T, const int32_t* frame_pos, const int32_t* frame_cnt, int Lm,
+                              float* mel, int Tm, int64_t* labels, si_stream_t stream);
 
 /* Splice GIVEN codewords: mel[b, :, pos_b + j] = C[labels[b, j]] -- the script's `expected_inpaint` branch, which puts the
  * ground-truth centroids where si_codebook_splice puts the predicted ones (I_ea/predict.py:177-189: all_embeds_t_c[0, labels]
@@ -272,6 +294,12 @@ int si_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const float* 
 int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch, float* wav_out,
                        void* workspace, size_t workspace_bytes, si_stream_t stream);
 
+/* Ragged batches: clip b holds mel_len[b] (HOST int32 (B), 1..Tm) frames of its (D, Tm) slab.  The stretch clamps at the clip's
+ * own last frame and every convolution's zero padding begins at its own end, so the first si_vocoder_samples(mel_len[b]) samples
+ * of row b equal that clip's waveform alone; the rest of the row (rows are si_vocoder_samples(Tm) long) is zero. */
+int si_hifigan_forward_varlen(si_ctx* ctx, const float* mel, const int32_t* mel_len, int B, int Tm, int stretch, float* wav_out,
+                              void* workspace, size_t workspace_bytes, si_stream_t stream);
+
 /* Log-mel front-end of the vocoder side.  wave22: device fp32 (B, N22), the RAW 22.05 kHz clip.  Per clip the span
  * [mask_start[b], mask_end[b]) (device int32, samples; both NULL = no masking) is zeroed, the clip is divided by its
  * max |x| and scaled by 0.95 (normalize != 0; I_ea/predict.py:99-104), then get_mel (I_ea/dataset/mel_dump.py:40-98,
@@ -282,6 +310,11 @@ int si_mel_frames(int n22);                              /* (n22 + 2*312 - 1024)
 int si_mel_workspace_bytes(si_ctx* ctx, int B, int N22, size_t* out);
 int si_mel_frontend(si_ctx* ctx, const float* wave22, const int32_t* mask_start, const int32_t* mask_end, int normalize,
                     int B, int N22, float* mel_out, void* workspace, size_t workspace_bytes, si_stream_t stream);
+
+/* Ragged batches: clip b holds sample_len[b] (HOST int32 (B)) samples of its row of N22; peak, reflect padding and frame count
+ * are the clip's own.  mel_out (B, 80, si_mel_frames(N22)): frames >= si_mel_frames(sample_len[b]) of clip b are zero. */
+int si_mel_frontend_varlen(si_ctx* ctx, const float* wave22, const int32_t* mask_start, const int32_t* mask_end, const int32_t* sample_len,
+                           int normalize, int B, int N22, float* mel_out, void* workspace, size_t workspace_bytes, si_stream_t stream);
 
 /* Shape helpers (host arithmetic only). */
 int si_num_frames(const si_ctx* ctx, int N);            /* encoder frames T for N samples, <0 on error */

@@ -72,16 +72,16 @@ def load_audio(path: str, sr: int) -> np.ndarray:
 
 def to_int16_pcm(audio: torch.Tensor, clip: bool = False) -> np.ndarray:
     """B6, the script's own two statements (I_ea/predict.py:204-206): `audio * 32768` in fp32, then numpy
-    `.astype('int16')` -- truncation toward zero, no rounding, NO clipping.  The generator ends in tanh, so the product lies
-    in [-32768, 32768]; only an exact +1.0 sample is out of int16's range, and there this function does what the
-    reference's cast does (same numpy call on the same fp32 value), so the PCM is bit-identical for every input.
+    `.astype('int16')` -- truncation toward zero, no rounding.  The generator ends in tanh, so the product lies in
+    [-32768, 32768]; only an exact +1.0 sample (tanhf saturates for pre-activations above ~9) is out of int16's range, and a
+    float -> int16 cast of 32768.0 is undefined behaviour in C and numpy (x86 scalar code gives -32768: a full-scale negative
+    click).  That ONE value is pinned to 32767; everywhere the reference's cast is defined the PCM is bit-identical to it.  The
+    GPU form of the same statement is `InpaintingEngine.to_int16` (si_pcm16).
     clip=True is an opt-in deviation for callers who feed waveforms that did not come out of the generator: values are
     clamped to [-32768, 32767] before the cast."""
     a = audio.detach().float().cpu() * MAX_WAV_VALUE
-    if clip:
-        a = a.clamp(-32768.0, 32767.0)
-    with np.errstate(invalid="ignore"):
-        return a.numpy().astype("int16")
+    a = a.clamp(-32768.0, 32767.0) if clip else a.clamp(max=32767.0)
+    return a.numpy().astype("int16")
 
 
 def write_wav(path: str, pcm_or_float: np.ndarray, sr: int):

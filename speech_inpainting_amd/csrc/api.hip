@@ -65,6 +65,7 @@ struct si_ctx {
     Layout lay;
     char* wdev = nullptr;
     bool weights_ready = false;
+    bool weights_verified = false;           // the blob's layout fingerprint has been compared with this context's (si_weights_check)
     std::map<std::string, long> dbg_size;                        // floats of each intermediate of the last forward
     std::map<std::string, std::pair<float*, long>> dbg_capture;  // name -> (device dst, capacity in floats)
     // per-launch HIP-event timing (si_profile_start / si_profile_stop)
@@ -87,6 +88,14 @@ struct si_ctx {
     // Hann window, transposed Slaney mel basis with the non-zero bin span of every band
     char* fe_dev = nullptr;
     size_t fe_dft = 0, fe_hann = 0, fe_basis = 0, fe_lo = 0, fe_hi = 0;
+    // ragged batches: per-clip length tables are built on the host (launch grids depend on them) and reach the device through a
+    // small ring of pinned staging slots (an async copy from pageable memory may still be reading its source after the call returns)
+    std::vector<int32_t> vl_host;            // the table of the call in progress (launchers read it during the call only)
+    static constexpr int VL_SLOTS = 4;
+    int32_t* vl_pin[VL_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    size_t vl_pin_ints[VL_SLOTS] = {0, 0, 0, 0};
+    hipEvent_t vl_ev[VL_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    int vl_next = 0;
 };
 
 static char g_create_err[512] = "";
@@ -152,6 +161,24 @@ int si_num_cus(si_ctx* ctx) {
         ctx->num_cus = n;
     }
     return ctx->num_cus;
+}
+// host table (ctx->vl_host) -> device `dst`, stream-ordered, through the next pinned slot
+static int vl_upload(si_ctx* ctx, int32_t* dst, hipStream_t st) {
+    const size_t n = ctx->vl_host.size();
+    const int slot = ctx->vl_next;
+    ctx->vl_next = (slot + 1) % si_ctx::VL_SLOTS;
+    if (!ctx->vl_ev[slot]) SI_HIP_CHECK(hipEventCreateWithFlags(&ctx->vl_ev[slot], hipEventDisableTiming));
+    else SI_HIP_CHECK(hipEventSynchronize(ctx->vl_ev[slot]));                  // the copy that last used this slot has finished
+    if (ctx->vl_pin_ints[slot] < n) {
+        if (ctx->vl_pin[slot]) SI_HIP_CHECK(hipHostFree(ctx->vl_pin[slot]));
+        ctx->vl_pin[slot] = nullptr; ctx->vl_pin_ints[slot] = 0;
+        SI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ctx->vl_pin[slot]), std::max<size_t>(n, 4096) * sizeof(int32_t), hipHostMallocDefault));
+        ctx->vl_pin_ints[slot] = std::max<size_t>(n, 4096);
+    }
+    memcpy(ctx->vl_pin[slot], ctx->vl_host.data(), n * sizeof(int32_t));
+    SI_HIP_CHECK(hipMemcpyAsync(dst, ctx->vl_pin[slot], n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    SI_HIP_CHECK(hipEventRecord(ctx->vl_ev[slot], st));
+    return SI_OK;
 }
 void si_prof_end(si_ctx* ctx, hipStream_t st) {
     if (ctx->prof_open < 0) return;
@@ -256,6 +283,24 @@ int plan_layout(si_ctx* ctx) {
     L.total = P.cur;
     return SI_OK;
 }
+
+// The packed blob's layout is a function of the model desc AND of the context's arithmetic-path options (stage_channels: the
+// padded widths of the fp16 stream).  A rank that receives the blob by broadcast must have planned the SAME layout as the rank
+// that packed it; the first 32 bytes of the blob (offset 0 is reserved) carry a fingerprint of the plan so that a mismatch is an
+// error instead of silently mis-read weights.
+struct BlobHeader { uint32_t magic, version; uint64_t fingerprint, total; uint64_t reserved; };
+constexpr uint32_t BLOB_MAGIC = 0x42574953u;   // "SIWB"
+uint64_t layout_fingerprint(const si_ctx* ctx) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) { const unsigned char* b = static_cast<const unsigned char*>(p); for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+    mix(&ctx->d, sizeof(ctx->d));
+    const Layout& L = ctx->lay;
+    const uint64_t total = L.total; mix(&total, 8);
+    for (int i = 0; i < ctx->d.num_ups; ++i) { const int c = stage_channels(ctx, i); mix(&c, 4); mix(&L.ups[i].w, sizeof(size_t)); }
+    mix(&L.post_w, sizeof(size_t)); mix(&L.post_C, 4); mix(&L.cb_raw, sizeof(size_t)); mix(&L.head.w, sizeof(size_t));
+    return h;
+}
+BlobHeader blob_header(const si_ctx* ctx) { return BlobHeader{BLOB_MAGIC, (uint32_t)SI_ABI_VERSION, layout_fingerprint(ctx), (uint64_t)ctx->lay.total, 0}; }
 
 int check_desc(si_ctx* ctx, const si_model_desc* d) {
     if (!d || d->struct_size != (int32_t)sizeof(si_model_desc))
@@ -554,7 +599,8 @@ size_t encoder_ws_bytes(const si_model_desc& d, int B, int N) {
                (size_t)B * d.conv_dim[0] * 2;
     // bf16 operand-ready copies (encoder in bf16 mode): LN(features), hidden, attention output, FFN intermediate
     const size_t h16 = (BT * d.conv_dim[d.num_conv - 1] + 2 * BT * d.hidden_size + BT * d.intermediate_size) * 2;
-    return f * 4 + h16 + (size_t)B * 16 + (size_t)B * 4 + si_conv0_partials_bytes(B, N) + 41 * 256;
+    return f * 4 + h16 + (size_t)B * 16 + (size_t)B * 4 + si_conv0_partials_bytes(B, N) + 41 * 256 +
+           align_up((size_t)(SI_MAX_CONV + 3) * (B + 1) * 4, 256);    // ragged batches: per-layer length table + row offsets
 }
 
 // Clips per vocoder pass.  Measured on MI355X (B = 32, fp32): 4 -> 109 ms/step, 8 -> 93, 16 -> 89, 32 -> 88: small
@@ -573,7 +619,7 @@ size_t vocoder_ws_bytes(const si_ctx* ctx, int B, int Tm, int stretch) {
     for (int i = 0; i < d.num_ups; ++i) { L *= d.up_rates[i]; c = stage_channels(ctx, i); lc_max = std::max(lc_max, (size_t)L * c); }
     // 6 fp32 activation buffers + 6 half-size buffers for the operand-ready 16-bit copies (bf16 / fp16 modes)
     const size_t f = (size_t)Bc * Tout * ctx->lay.mel_ld + 9 * (size_t)Bc * lc_max;
-    return f * 4 + 32 * 256;
+    return f * 4 + 32 * 256 + align_up((size_t)(2 * SI_MAX_UPS + 3) * B * 4, 256);   // ragged batches: per-stage length table
 }
 
 TapGemmParams gemm_params(const si_ctx* ctx, const GemmW& G) {
@@ -606,7 +652,7 @@ const float* wf(const si_ctx* ctx, size_t off) { return reinterpret_cast<const f
 
 static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len, const int32_t* valid_len,
                       int normalize, float norm_eps, const double* pre_add, int output_layer, int B, int N, float* out_feats, float* out_hidden,
-                      void* workspace, size_t workspace_bytes, si_stream_t stream);
+                      void* workspace, size_t workspace_bytes, si_stream_t stream, const int32_t* host_len = nullptr);
 
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" {
@@ -645,6 +691,10 @@ void si_destroy(si_ctx* ctx) {
     if (ctx->wdev) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->wdev); }
     if (ctx->fe_dev) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->fe_dev); }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < si_ctx::VL_SLOTS; ++i) {
+        if (ctx->vl_ev[i]) { (void)hipEventSynchronize(ctx->vl_ev[i]); (void)hipEventDestroy(ctx->vl_ev[i]); }
+        if (ctx->vl_pin[i]) (void)hipHostFree(ctx->vl_pin[i]);
+    }
     delete ctx;
 }
 
@@ -653,6 +703,7 @@ int si_alloc_weights(si_ctx* ctx) {
     SI_HIP_CHECK(hipSetDevice(ctx->device));
     if (!ctx->wdev) SI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->wdev), ctx->lay.total));
     ctx->weights_ready = true;          // bytes arrive by broadcast before the first forward
+    ctx->weights_verified = false;      // ... and are checked against this context's layout then (si_weights_check)
     return SI_OK;
 }
 
@@ -666,8 +717,26 @@ int si_load_weights(si_ctx* ctx, const void* host_blob, size_t nbytes, const cha
     if (rc) return rc;
     SI_HIP_CHECK(hipSetDevice(ctx->device));
     if (!ctx->wdev) SI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->wdev), ctx->lay.total));
+    const BlobHeader hd = blob_header(ctx);
+    memcpy(P.out.data(), &hd, sizeof(hd));
     SI_HIP_CHECK(hipMemcpy(ctx->wdev, P.out.data(), ctx->lay.total, hipMemcpyHostToDevice));
     ctx->weights_ready = true;
+    ctx->weights_verified = true;
+    return SI_OK;
+}
+
+int si_weights_check(si_ctx* ctx) {
+    if (!ctx) return SI_EINVAL;
+    if (!ctx->wdev) return si_fail(ctx, SI_ESTATE, "weights are not allocated: call si_load_weights or si_alloc_weights first");
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    BlobHeader got{};
+    SI_HIP_CHECK(hipMemcpy(&got, ctx->wdev, sizeof(got), hipMemcpyDeviceToHost));
+    const BlobHeader want = blob_header(ctx);
+    if (got.magic != want.magic || got.version != want.version || got.fingerprint != want.fingerprint || got.total != want.total)
+        return si_fail(ctx, SI_EWEIGHTS, "the weight blob in this context was packed for a different layout (fingerprint %016llx / %llu bytes, this "
+                       "context plans %016llx / %llu): the source rank's model desc or SI_VOC_* environment differs, or the broadcast has not arrived",
+                       (unsigned long long)got.fingerprint, (unsigned long long)got.total, (unsigned long long)want.fingerprint, (unsigned long long)want.total);
+    ctx->weights_verified = true;
     return SI_OK;
 }
 
@@ -709,6 +778,14 @@ int si_hubert_forward_padded(si_ctx* ctx, const float* wav, const int32_t* mask_
                       workspace_bytes, stream);
 }
 
+int si_hubert_forward_varlen(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len, const int32_t* sample_len,
+                             int normalize, int B, int N, float* out_feats, void* workspace, size_t workspace_bytes, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!out_feats || !sample_len) return si_fail(ctx, SI_EINVAL, "si_hubert_forward_varlen: NULL argument");
+    return hubert_run(ctx, wav, mask_start, mask_len, nullptr, normalize, 1e-7f, nullptr, 0, B, N, out_feats, nullptr, workspace, workspace_bytes,
+                      stream, sample_len);
+}
+
 int si_hubert_extract_features(si_ctx* ctx, const si_extract_desc* x, const float* wav, const int32_t* mask_start, const int32_t* mask_len,
                                const double* pre_mask_add, int B, int N, float* out_hidden, void* workspace, size_t workspace_bytes,
                                si_stream_t stream) {
@@ -735,10 +812,13 @@ int si_code_splice(si_ctx* ctx, const int64_t* code_clean, const int64_t* code_m
 // The encoder.  output_layer = 0: all layers [+ the stable flavour's final LayerNorm] + final_layers -> out_feats (B, T, codebook_dim).
 // output_layer = L >= 1: stop after L transformer layers and copy the hidden state (the residual stream in the pre-LN flavour, the
 // layer's output LayerNorm in the post-LN one) to out_hidden (B, T, H) -- fairseq's extract_features(output_layer = L).
+// host_len (B, HOST) or null: ragged batch -- clip b holds host_len[b] samples of its row of N; each clip's result equals that clip
+// run alone (conv0 statistics over its own rows, convolutions stop at its own lengths, the transformer runs on PACKED rows).
 static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, const int32_t* mask_len, const int32_t* valid_len,
                       int normalize, float norm_eps, const double* pre_add, int output_layer, int B, int N, float* out_feats, float* out_hidden,
-                      void* workspace, size_t workspace_bytes, si_stream_t stream) {
+                      void* workspace, size_t workspace_bytes, si_stream_t stream, const int32_t* host_len) {
     if (!ctx->weights_ready) return si_fail(ctx, SI_ESTATE, "si_hubert_forward before weights were loaded");
+    if (!ctx->weights_verified) if (int rcw = si_weights_check(ctx)) return rcw;      // a received blob: once, before its first use
     if (!wav || !workspace || B <= 0) return si_fail(ctx, SI_EINVAL, "si_hubert_forward: NULL / empty argument");
     const si_model_desc& d = ctx->d;
     const Layout& L = ctx->lay;
@@ -749,13 +829,43 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
         return si_fail(ctx, SI_ENOMEM, "workspace of %zu bytes < %zu needed for B=%d N=%d", workspace_bytes, encoder_ws_bytes(d, B, N), B, N);
     SI_HIP_CHECK(hipSetDevice(ctx->device));
     const int T = e.T, H = d.hidden_size, I = d.intermediate_size, CF = d.conv_dim[d.num_conv - 1];
-    const long BT = (long)B * T;
     size_t cmax = 0;
     for (int i = 0; i < d.num_conv; ++i) cmax = std::max(cmax, (size_t)e.L[i + 1] * d.conv_dim[i]);
 
     Carver W{static_cast<char*>(workspace), workspace_bytes};
+    // ---- ragged batch: the table [samples | L_1 .. L_nconv | row offsets (B + 1)] on the host and on the device
+    const bool vl = host_len != nullptr;
+    const int32_t* h_tab = nullptr;      // host
+    int32_t* d_tab = nullptr;            // device
+    long rows_packed = 0;
+    double sum_t2 = 0.0;
+    if (vl) {
+        if (valid_len || output_layer) return si_fail(ctx, SI_EINVAL, "ragged batches: not combined with padded batches or output_layer");
+        if (d.codebook_dim % 4) return si_fail(ctx, SI_EINVAL, "ragged batches need codebook_dim %% 4 == 0");
+        std::vector<int32_t>& tab = ctx->vl_host;
+        tab.assign((size_t)(d.num_conv + 1) * B + B + 1, 0);
+        for (int b = 0; b < B; ++b) {
+            if (host_len[b] < 1 || host_len[b] > N) return si_fail(ctx, SI_EINVAL, "ragged batch: clip %d holds %d samples, outside 1..%d", b, host_len[b], N);
+            const EncDims eb = enc_dims(d, host_len[b]);
+            if (eb.T < 1) return si_fail(ctx, SI_EINVAL, "ragged batch: clip %d (%d samples) is shorter than the conv stack's receptive field", b, host_len[b]);
+            for (int i = 0; i <= d.num_conv; ++i) tab[(size_t)i * B + b] = eb.L[i];
+            tab[(size_t)(d.num_conv + 1) * B + b] = (int32_t)rows_packed;
+            rows_packed += eb.T;
+            sum_t2 += (double)eb.T * eb.T;
+        }
+        tab[(size_t)(d.num_conv + 1) * B + B] = (int32_t)rows_packed;
+        d_tab = reinterpret_cast<int32_t*>(W.bytes(tab.size() * 4));
+        if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: encoder workspace carve exceeded its own estimate");
+        if (int rc = vl_upload(ctx, d_tab, st)) return rc;
+        h_tab = tab.data();
+        valid_len = d_tab;                                   // the statistics and loaders of conv0 stop at each clip's own samples
+    }
+    auto dL = [&](int i) { return d_tab + (size_t)i * B; };            // device / host rows of conv layer i's output (0: samples)
+    auto hL = [&](int i) { return h_tab + (size_t)i * B; };
+    const int32_t* d_rowoff = vl ? d_tab + (size_t)(d.num_conv + 1) * B : nullptr;
+    const long BT = vl ? rows_packed : (long)B * T;          // transformer rows
     double* stats = reinterpret_cast<double*>(W.bytes((size_t)B * 16));
-    int32_t* vframes = valid_len ? reinterpret_cast<int32_t*>(W.bytes((size_t)B * 4)) : nullptr;
+    int32_t* vframes = (valid_len && !vl) ? reinterpret_cast<int32_t*>(W.bytes((size_t)B * 4)) : nullptr;
     double* partials = reinterpret_cast<double*>(W.bytes(si_conv0_partials_bytes(B, N)));
     float* affine = W.floats((size_t)B * d.conv_dim[0] * 2);
     float* cbuf[2] = {W.floats((size_t)B * cmax), W.floats((size_t)B * cmax)};
@@ -784,9 +894,10 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
 
     int rc;
     // A0 + A1: normalise fused into conv0
-    WaveNormParams wp{wav, mask_start, mask_len, B, N, e.L[1], d.conv_dim[0], d.conv_kernel[0], d.conv_stride[0], normalize, valid_len, norm_eps, pre_add};
+    WaveNormParams wp{wav, mask_start, mask_len, B, N, e.L[1], d.conv_dim[0], d.conv_kernel[0], d.conv_stride[0], normalize, valid_len, norm_eps, pre_add,
+                      vl ? dL(1) : nullptr};
     if ((rc = si_launch_wave_stats(ctx, wp, stats, st))) return rc;
-    if (valid_len && (rc = si_launch_frame_lengths(ctx, valid_len, B, d.num_conv, d.conv_kernel, d.conv_stride, e.T, vframes, st))) return rc;
+    if (vframes && (rc = si_launch_frame_lengths(ctx, valid_len, B, d.num_conv, d.conv_kernel, d.conv_stride, e.T, vframes, st))) return rc;
     // layer-norm flavour (HuBERT-large) in bf16 mode: every conv is followed by LayerNorm + GELU over its 512 channels; the
     // LayerNorm writes ONLY the bf16 operand of the next conv (the rounding that conv would apply while staging), into the
     // other buffer (its bf16 rows would overlap unread fp32 rows of its own input), so that the convolutions run on the
@@ -819,6 +930,11 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
         p.olimit = p.o_seg_stride;
         p.act = d.feat_norm_layer ? SI_ACT_NONE : SI_ACT_GELU;
         p.lingemm = ctx->opt_enc_lingemm;
+        if (vl) {                                            // each clip's own input / output rows (modeling_hubert.py:664-677)
+            p.seg_lin = dL(i); p.seg_m = dL(i + 1); p.seg_orows = dL(i + 1); p.olim_mul = p.ldo; p.seg_m_host = hL(i + 1);
+            double rows = 0; for (int b = 0; b < B; ++b) rows += hL(i + 1)[b];
+            p.algo_macs = rows * d.conv_dim[i] * (double)d.conv_dim[i - 1] * d.conv_kernel[i];
+        }
         if ((rc = si_launch_tapgemm(ctx, c.g.math, p, st))) return rc;
         if (l16) {
             const bool last = i + 1 == d.num_conv;
@@ -834,6 +950,10 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
             return rc;
     }
     const float* feat = cbuf[cur];                                   // (B, T, CF)
+    if (vl) {                                                        // -> packed rows (sum of T_b, CF): everything behind is row-wise
+        if ((rc = si_launch_repack_rows(ctx, cbuf[cur], cbuf[cur ^ 1], B, T, CF, d_rowoff, false, st))) return rc;
+        feat = cbuf[cur ^ 1];
+    }
     if ((rc = si_tap(ctx, "features", feat, BT * CF, st))) return rc;
     // A3: LN + projection
     const float* pin = feat;
@@ -853,6 +973,10 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
         p.nseg = B; p.Lin = T; p.M = T; p.ldx = H; p.x_seg_stride = (long)T * H;
         p.pad = d.pos_conv_kernel / 2; p.ldo = H; p.o_seg_stride = (long)T * H; p.olimit = p.o_seg_stride;
         p.act = SI_ACT_GELU;
+        if (vl) {                                            // packed rows: the conv's zero padding begins at each clip's own last frame
+            p.seg_lin = dL(d.num_conv); p.seg_m = dL(d.num_conv); p.seg_orows = dL(d.num_conv); p.olim_mul = H; p.seg_row_off = d_rowoff;
+            p.algo_macs = (double)BT * H * (double)(H / d.pos_conv_groups) * d.pos_conv_kernel;
+        }
         if ((rc = si_launch_tapgemm(ctx, L.pos.math, p, st))) return rc;
     }
     const float eps = d.layer_norm_eps;
@@ -867,8 +991,8 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
         const LayerW& Wl = L.layers[l];
         if (!d.stable_layer_norm) {       // post-LN (modeling_hubert.py:371-404); h16 = bf16(h) when e16
             if ((rc = linear(ctx, Wl.qkv, h, qkv_bf16 ? nullptr : qkv, BT, SI_ACT_NONE, nullptr, st, h16, qkv_bf16 ? qkv16 : nullptr))) return rc;
-            if (qkv_bf16) rc = si_launch_attention_bf16in(ctx, qkv16, B, T, H, d.num_heads, st, att16, vframes);
-            else rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16, vframes);
+            if (qkv_bf16) rc = si_launch_attention_bf16in(ctx, qkv16, B, T, H, d.num_heads, st, att16, vframes, d_rowoff, sum_t2);
+            else rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16, vframes, d_rowoff, sum_t2);
             if (rc) return rc;
             if ((rc = linear(ctx, Wl.out, att, h2, BT, SI_ACT_NONE, h, st, att16))) return rc;
             if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h, BT, H, eps, 0, st, h16))) return rc;
@@ -878,8 +1002,8 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
         } else {                          // pre-LN "stable" (modeling_hubert.py:504-547); residual adds are in place
             if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h2, BT, H, eps, 0, st, h16))) return rc;
             if ((rc = linear(ctx, Wl.qkv, h2, qkv_bf16 ? nullptr : qkv, BT, SI_ACT_NONE, nullptr, st, h16, qkv_bf16 ? qkv16 : nullptr))) return rc;
-            if (qkv_bf16) rc = si_launch_attention_bf16in(ctx, qkv16, B, T, H, d.num_heads, st, att16, vframes);
-            else rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16, vframes);
+            if (qkv_bf16) rc = si_launch_attention_bf16in(ctx, qkv16, B, T, H, d.num_heads, st, att16, vframes, d_rowoff, sum_t2);
+            else rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16, vframes, d_rowoff, sum_t2);
             if (rc) return rc;
             if ((rc = linear(ctx, Wl.out, att, h, BT, SI_ACT_NONE, h, st, att16))) return rc;
             if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h2, BT, H, eps, 0, st, h16))) return rc;
@@ -900,7 +1024,10 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     if ((rc = si_tap(ctx, "last_hidden", h, BT * H, st))) return rc;
     // A9: final_layers = LN -> Linear(H, codebook_dim), always fp32
     if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, L.head_ln_g), wf(ctx, L.head_ln_b), h2, BT, H, 1e-5f, 0, st))) return rc;
-    return linear(ctx, L.head, h2, out_feats, BT, SI_ACT_NONE, nullptr, st);
+    if (!vl) return linear(ctx, L.head, h2, out_feats, BT, SI_ACT_NONE, nullptr, st);
+    // ragged batch: the head on the packed rows (into the dead q|k|v storage), then out to (B, T, D) with zero rows past each clip
+    if ((rc = linear(ctx, L.head, h2, qkv, BT, SI_ACT_NONE, nullptr, st))) return rc;
+    return si_launch_repack_rows(ctx, qkv, out_feats, B, T, d.codebook_dim, d_rowoff, true, st);
 }
 
 extern "C" {
@@ -909,6 +1036,7 @@ int si_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, const int3
                        int64_t* labels, si_stream_t stream) {
     if (!ctx) return SI_EINVAL;
     if (!ctx->weights_ready) return si_fail(ctx, SI_ESTATE, "si_codebook_splice before weights were loaded");
+    if (!ctx->weights_verified) if (int rcw = si_weights_check(ctx)) return rcw;
     if (!feats || !frame_pos || !mel || B <= 0 || Lm < 0) return si_fail(ctx, SI_EINVAL, "si_codebook_splice: NULL / empty argument");
     if (ctx->d.codebook_dim != ctx->d.num_mels)
         return si_fail(ctx, SI_EINVAL, "codebook_dim %d != generator input width %d: centroids are not frames of this generator's input",
@@ -917,6 +1045,19 @@ int si_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, const int3
     const Layout& L = ctx->lay;
     return si_launch_codebook_splice(ctx, feats, B, T, ctx->d.codebook_dim, frame_pos, Lm, wf(ctx, L.cb_centered), wf(ctx, L.cb_raw),
                                      wf(ctx, L.cb_rnorm), ctx->d.num_clusters, mel, Tm, labels, static_cast<hipStream_t>(stream));
+}
+
+int si_codebook_splice_varlen(si_ctx* ctx, const float* feats, int B, int T, const int32_t* frame_pos, const int32_t* frame_cnt, int Lm,
+                              float* mel, int Tm, int64_t* labels, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!ctx->weights_ready) return si_fail(ctx, SI_ESTATE, "si_codebook_splice_varlen before weights were loaded");
+    if (!feats || !frame_pos || !frame_cnt || !mel || B <= 0 || Lm < 0) return si_fail(ctx, SI_EINVAL, "si_codebook_splice_varlen: NULL / empty argument");
+    if (ctx->d.codebook_dim != ctx->d.num_mels)
+        return si_fail(ctx, SI_EINVAL, "codebook_dim %d != generator input width %d", ctx->d.codebook_dim, ctx->d.num_mels);
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    const Layout& L = ctx->lay;
+    return si_launch_codebook_splice(ctx, feats, B, T, ctx->d.codebook_dim, frame_pos, Lm, wf(ctx, L.cb_centered), wf(ctx, L.cb_raw),
+                                     wf(ctx, L.cb_rnorm), ctx->d.num_clusters, mel, Tm, labels, static_cast<hipStream_t>(stream), frame_cnt);
 }
 
 int si_codebook_splice_labels(si_ctx* ctx, const int64_t* labels, int B, const int32_t* frame_pos, int Lm, float* mel, int Tm,
@@ -1073,10 +1214,28 @@ int si_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const float* 
     return si_launch_resample_poly(ctx, x, B, n_in, taps, ntaps, up, down, pre_remove, n_out, y, static_cast<hipStream_t>(stream));
 }
 
+static int hifigan_run(si_ctx* ctx, const float* mel, int B, int Tm, int stretch, float* wav_out, void* workspace,
+                       size_t workspace_bytes, si_stream_t stream, const int32_t* host_len);
+
 int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch, float* wav_out, void* workspace,
                        size_t workspace_bytes, si_stream_t stream) {
+    return hifigan_run(ctx, mel, B, Tm, stretch, wav_out, workspace, workspace_bytes, stream, nullptr);
+}
+
+int si_hifigan_forward_varlen(si_ctx* ctx, const float* mel, const int32_t* mel_len, int B, int Tm, int stretch, float* wav_out, void* workspace,
+                              size_t workspace_bytes, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!mel_len) return si_fail(ctx, SI_EINVAL, "si_hifigan_forward_varlen: NULL lengths");
+    return hifigan_run(ctx, mel, B, Tm, stretch, wav_out, workspace, workspace_bytes, stream, mel_len);
+}
+
+// host_len (B, HOST) or null: ragged batch -- clip b holds host_len[b] mel frames of its Tm; every convolution's zero padding
+// begins at the clip's OWN end, so its waveform equals that clip's alone; wav_out rows are the longest clip's, zero past each clip.
+static int hifigan_run(si_ctx* ctx, const float* mel, int B, int Tm, int stretch, float* wav_out, void* workspace,
+                       size_t workspace_bytes, si_stream_t stream, const int32_t* host_len) {
     if (!ctx) return SI_EINVAL;
     if (!ctx->weights_ready) return si_fail(ctx, SI_ESTATE, "si_hifigan_forward before weights were loaded");
+    if (!ctx->weights_verified) if (int rcw = si_weights_check(ctx)) return rcw;
     if (!mel || !wav_out || !workspace || B <= 0 || Tm <= 0) return si_fail(ctx, SI_EINVAL, "si_hifigan_forward: NULL / empty argument");
     const si_model_desc& d = ctx->d;
     const Layout& Ly = ctx->lay;
@@ -1094,6 +1253,32 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
     }
     const long Lwav = si_vocoder_samples(ctx, Tm, stretch);
     Carver W{static_cast<char*>(workspace), workspace_bytes};
+    // ---- ragged batch: the table [mel frames | rows of stage 0 (stretched frames) .. stage num_ups | GEMM rows of upsampler 1 .. num_ups]
+    const bool vl = host_len != nullptr;
+    const int32_t* h_tab = nullptr;
+    int32_t* d_tab = nullptr;
+    if (vl) {
+        std::vector<int32_t>& tab = ctx->vl_host;
+        tab.assign((size_t)(2 * d.num_ups + 2) * B, 0);
+        for (int b = 0; b < B; ++b) {
+            if (host_len[b] < 1 || host_len[b] > Tm) return si_fail(ctx, SI_EINVAL, "ragged batch: clip %d holds %d mel frames, outside 1..%d", b, host_len[b], Tm);
+            long Lb = voc_tout(host_len[b], stretch);
+            if (Lb < 1) return si_fail(ctx, SI_EINVAL, "ragged batch: clip %d (%d mel frames) stretches to nothing", b, host_len[b]);
+            tab[b] = host_len[b];
+            tab[(size_t)B + b] = (int32_t)Lb;
+            for (int i = 0; i < d.num_ups; ++i) {
+                const int u = d.up_rates[i], pad = (d.up_kernels[i] - u) / 2;
+                Lb *= u;
+                tab[(size_t)(2 + i) * B + b] = (int32_t)Lb;
+                tab[(size_t)(2 + d.num_ups + i) * B + b] = (int32_t)((pad + Lb - 1) / u + 1);
+            }
+        }
+        d_tab = reinterpret_cast<int32_t*>(W.bytes(tab.size() * 4));
+        if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: vocoder workspace carve exceeded its own estimate");
+        if (int rc = vl_upload(ctx, d_tab, st)) return rc;
+        h_tab = tab.data();
+        SI_HIP_CHECK(hipMemsetAsync(wav_out, 0, (size_t)B * Lwav * sizeof(float), st));   // samples past a clip's own end read as silence
+    }
     float* ext_ws = W.floats((size_t)Bc_max * Tout * Ly.mel_ld);
     float* buf_ws[6];
     unsigned short* h16_ws[6];
@@ -1119,8 +1304,17 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
     // the generator on clips [b0, b0 + Bc) with its own scratch, enqueued on stream `st`
     auto run = [&](int b0, int Bc, float* ext, float* const* buf, unsigned short* const* h16, hipStream_t st) -> int {
         int rc;
+        // ragged batch: device / host rows of the chunk's clips -- dTm mel frames, dLs(s) rows at stage s (0 = stretched frames), dMt(i) GEMM rows of upsampler i
+        const int32_t* dTm = vl ? d_tab + b0 : nullptr;
+        auto dLs = [&](int sidx) -> const int32_t* { return vl ? d_tab + (size_t)(1 + sidx) * B + b0 : nullptr; };
+        auto hLs = [&](int sidx) -> const int32_t* { return vl ? h_tab + (size_t)(1 + sidx) * B + b0 : nullptr; };
+        auto dMt = [&](int i) -> const int32_t* { return vl ? d_tab + (size_t)(2 + d.num_ups + i) * B + b0 : nullptr; };
+        auto hMt = [&](int i) -> const int32_t* { return vl ? h_tab + (size_t)(2 + d.num_ups + i) * B + b0 : nullptr; };
+        auto rows_of = [&](const int32_t* h, long uniform) { if (!h) return (double)Bc * uniform; double r = 0; for (int b = 0; b < Bc; ++b) r += h[b]; return r; };
+        // a same-length convolution at stage sidx: every clip reads and writes its own rows
+        auto seg_conv = [&](TapGemmParams& q, int sidx) { if (vl) { q.seg_lin = q.seg_m = q.seg_orows = dLs(sidx); q.olim_mul = q.ldo; q.seg_m_host = hLs(sidx); } };
         // A14: stretch + transpose to channels-last
-        if ((rc = si_launch_extend_mel(ctx, mel + (size_t)b0 * d.num_mels * Tm, Bc, d.num_mels, Tm, (int)Tout, stretch, ext, Ly.mel_ld, st))) return rc;
+        if ((rc = si_launch_extend_mel(ctx, mel + (size_t)b0 * d.num_mels * Tm, Bc, d.num_mels, Tm, (int)Tout, stretch, ext, Ly.mel_ld, st, dTm, dLs(0)))) return rc;
         // B1: conv_pre
         float* x = buf[0];
         float* xs = buf[1];
@@ -1131,8 +1325,9 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
             if (opr) { p.out16 = x16; p.out16_slope = r16 ? 1.f : 0.1f; }
             if (r16) p.out = nullptr;
             p.nseg = Bc; p.Lin = (int)Tout; p.M = (int)Tout; p.ldx = Ly.mel_ld; p.x_seg_stride = Tout * Ly.mel_ld;
-            p.algo_macs = (double)Bc * Tout * d.up_initial_channel * (double)d.num_mels * 7;
+            p.algo_macs = rows_of(hLs(0), Tout) * d.up_initial_channel * (double)d.num_mels * 7;
             p.pad = 3; p.ldo = d.up_initial_channel; p.o_seg_stride = Tout * d.up_initial_channel; p.olimit = p.o_seg_stride;
+            seg_conv(p, 0);
             if ((rc = si_launch_tapgemm(ctx, Ly.pre.math, p, st))) return rc;
         }
         long Lc = Tout; int c = d.up_initial_channel;
@@ -1149,6 +1344,7 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                 q.x16 = x16; q.w = reinterpret_cast<const unsigned short*>(ctx->wdev + G.w); q.bias = reinterpret_cast<const float*>(ctx->wdev + G.bias);
                 q.out16 = U16; q.B = Bc; q.Lin = (int)Lc; q.M = (int)((pad + Lo - 1) / u + 1); q.Cin = c; q.N = u * cout; q.taps = G.ntaps;
                 q.ooff = (long)pad * cout; q.o_clip_stride = Lo * cout; q.o_clip_elems = Lo * cout;
+                q.lens_lin = dLs(i); q.lens_m = dMt(i); q.lens_m_host = hMt(i);
                 if (G.has_bias && G.Npad == G.N && G.math == SI_MATH_F16) {
                     rc = si_launch_upsample_stream(ctx, q, st);
                     if (rc < 0) return rc;
@@ -1163,7 +1359,8 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                 p.nseg = Bc; p.Lin = (int)Lc; p.M = (int)((pad + Lo - 1) / u + 1); p.ldx = c; p.x_seg_stride = Lc * c;
                 p.dil = -1; p.ldo = u * cout; p.o_seg_stride = Lo * cout; p.ooff = -(long)pad * cout; p.olimit = Lo * cout;
                 p.pro_slope = (opr && !r16) ? 1.f : 0.1f;          // operand-ready inputs are already activated
-                p.algo_macs = (double)Bc * Lc * (double)(d.up_initial_channel >> i) * (double)(d.up_initial_channel >> (i + 1)) * k;   // Cin*Cout*k*Lin (real widths)
+                p.algo_macs = rows_of(hLs(i), Lc) * (double)(d.up_initial_channel >> i) * (double)(d.up_initial_channel >> (i + 1)) * k;   // Cin*Cout*k*Lin (real widths)
+                if (vl) { p.seg_lin = dLs(i); p.seg_m = dMt(i); p.seg_orows = dLs(i + 1); p.olim_mul = cout; p.seg_m_host = hMt(i); }
                 if ((rc = si_launch_tapgemm(ctx, Ly.ups[i].math, p, st))) return rc;
             }
             if (!r16 && (rc = si_tap(ctx, upn[i], U, (long)Bc * Lo * cout, st))) return rc;
@@ -1193,6 +1390,8 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                         q.nseg = Bc; q.Lin = (int)Lo; q.M = (int)Lo; q.ldx = cout; q.x_seg_stride = Lo * cout;
                         q.dil = dl; q.pad = dl * (rk - 1) / 2; q.ldo = cout; q.o_seg_stride = Lo * cout; q.olimit = q.o_seg_stride;
                         if (last) { q.alpha = 1.0f / nk; q.accumulate = (j > 0); q.acc16 = (r16 && j > 0); }
+                        seg_conv(q, i + 1);
+                        if (vl) q.algo_macs = rows_of(hLs(i + 1), Lo) * (double)cout * cout * rk;
                         if ((rc = si_launch_tapgemm(ctx, R.c1[n].math, q, st))) return rc;
                         y = ynext;
                         y16 = ynext16;
@@ -1203,6 +1402,7 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                     // full-rate stage: the whole resblock (three pairs) as one kernel, residual stream in LDS (reschain.hip)
                     ResChainParams cp{};
                     cp.y16 = U16; cp.out16 = xs16; cp.B = Bc; cp.L = (int)Lo; cp.k = rk; cp.alpha = 1.0f / nk; cp.accumulate = j > 0;
+                    cp.lens = dLs(i + 1); cp.lens_host = hLs(i + 1);
                     for (int n = 0; n < 3; ++n) {
                         const TapGemmParams w1 = gemm_params(ctx, R.c1[n]), w2 = gemm_params(ctx, R.c2[n]);
                         cp.w1[n] = static_cast<const unsigned short*>(w1.w); cp.w2[n] = static_cast<const unsigned short*>(w2.w);
@@ -1220,7 +1420,7 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                         const TapGemmParams w1 = gemm_params(ctx, R.c1[n]), w2 = gemm_params(ctx, R.c2[n]);
                         unsigned short* yn16 = last_n ? xs16 : h16[4 + (n & 1)];
                         const int frc = si_launch_respair(ctx, cout, y16, yn16, w1.w, w2.w, w1.bias, w2.bias, Bc, (int)Lo, rk, dl,
-                                                          last_n ? 1.0f / nk : 1.0f, last_n && j > 0, st);
+                                                          last_n ? 1.0f / nk : 1.0f, last_n && j > 0, st, dLs(i + 1), hLs(i + 1));
                         if (frc < 0) return frc;
                         if (frc == 0) { y16 = yn16; continue; }
                     }
@@ -1231,6 +1431,8 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                     p.pro_slope = (opr && !r16) ? 1.f : 0.1f;
                     p.nseg = Bc; p.Lin = (int)Lo; p.M = (int)Lo; p.ldx = cout; p.x_seg_stride = Lo * cout;
                     p.dil = dl; p.pad = dl * (rk - 1) / 2; p.ldo = cout; p.o_seg_stride = Lo * cout; p.olimit = p.o_seg_stride;
+                    seg_conv(p, i + 1);
+                    if (vl) p.algo_macs = rows_of(hLs(i + 1), Lo) * (double)cout * cout * rk;
                     if ((rc = si_launch_tapgemm(ctx, R.c1[n].math, p, st))) return rc;
                     const bool last = (n == d.num_dil - 1);
                     float* ynext = last ? xs : buf[4 + (n & 1)];
@@ -1249,6 +1451,8 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                     q.dil = 1; q.pad = (rk - 1) / 2; q.ldo = cout; q.o_seg_stride = Lo * cout; q.olimit = q.o_seg_stride;
                     q.pro_slope = opr ? 1.f : 0.1f;               // the intermediate is stored activated in the 16-bit modes
                     if (last) { q.alpha = 1.0f / nk; q.accumulate = (j > 0); q.acc16 = (r16 && j > 0); }
+                    seg_conv(q, i + 1);
+                    if (vl) q.algo_macs = rows_of(hLs(i + 1), Lo) * (double)cout * cout * rk;
                     if ((rc = si_launch_tapgemm(ctx, R.c2[n].math, q, st))) return rc;
                     y = ynext;
                     y16 = ynext16;
@@ -1261,7 +1465,7 @@ int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
         }
         // B4: leaky_relu(0.01) -> conv_post -> tanh
         return si_launch_conv_post(ctx, x, wf(ctx, Ly.post_w), wf(ctx, Ly.post_b), Bc, (int)Lc, c, 7, wav_out + (size_t)b0 * Lwav, st,
-                                   r16 ? x16 : nullptr);
+                                   r16 ? x16 : nullptr, dLs(d.num_ups), hLs(d.num_ups));
     };
 
     for (int b0 = 0; b0 < B; b0 += Bc_max) {
@@ -1355,7 +1559,8 @@ int ensure_frontend(si_ctx* ctx) {
 size_t mel_ws_bytes(int B, int N22) {
     const long Tm = (N22 + 2 * FE_PAD - FE_NFFT) / FE_HOP + 1;
     if (Tm < 1) return 0;
-    return fe_round((size_t)B * 4) + fe_round((size_t)B * Tm * FE_FRAME * 4) + fe_round((size_t)B * Tm * FE_LDSPEC * 4) + 256;
+    return fe_round((size_t)B * 4) + fe_round((size_t)B * Tm * FE_FRAME * 4) + fe_round((size_t)B * Tm * FE_LDSPEC * 4) + 256 +
+           fe_round((size_t)2 * B * 4);                               // ragged batches: the length table
 }
 
 }  // namespace
@@ -1370,8 +1575,24 @@ int si_mel_workspace_bytes(si_ctx* ctx, int B, int N22, size_t* out) {
     return SI_OK;
 }
 
+static int mel_run(si_ctx* ctx, const float* wave22, const int32_t* mask_start, const int32_t* mask_end, int normalize, int B,
+                   int N22, float* mel_out, void* workspace, size_t workspace_bytes, si_stream_t stream, const int32_t* host_len);
+
 int si_mel_frontend(si_ctx* ctx, const float* wave22, const int32_t* mask_start, const int32_t* mask_end, int normalize, int B,
                     int N22, float* mel_out, void* workspace, size_t workspace_bytes, si_stream_t stream) {
+    return mel_run(ctx, wave22, mask_start, mask_end, normalize, B, N22, mel_out, workspace, workspace_bytes, stream, nullptr);
+}
+
+int si_mel_frontend_varlen(si_ctx* ctx, const float* wave22, const int32_t* mask_start, const int32_t* mask_end, const int32_t* sample_len,
+                           int normalize, int B, int N22, float* mel_out, void* workspace, size_t workspace_bytes, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!sample_len) return si_fail(ctx, SI_EINVAL, "si_mel_frontend_varlen: NULL lengths");
+    return mel_run(ctx, wave22, mask_start, mask_end, normalize, B, N22, mel_out, workspace, workspace_bytes, stream, sample_len);
+}
+
+// host_len (B, HOST) or null: ragged batch -- clip b holds host_len[b] samples of its row of N22 (peak, reflection and frame count are its own)
+static int mel_run(si_ctx* ctx, const float* wave22, const int32_t* mask_start, const int32_t* mask_end, int normalize, int B,
+                   int N22, float* mel_out, void* workspace, size_t workspace_bytes, si_stream_t stream, const int32_t* host_len) {
     if (!ctx) return SI_EINVAL;
     if (!wave22 || !mel_out || !workspace || B <= 0) return si_fail(ctx, SI_EINVAL, "si_mel_frontend: NULL / empty argument");
     if ((mask_start == nullptr) != (mask_end == nullptr))
@@ -1388,10 +1609,25 @@ int si_mel_frontend(si_ctx* ctx, const float* wave22, const int32_t* mask_start,
     float* peak = W.floats((size_t)B);
     float* frames = W.floats((size_t)B * Tm * FE_FRAME);
     float* spec = W.floats((size_t)B * Tm * FE_LDSPEC);
+    const int32_t *d_n = nullptr, *d_tm = nullptr;
+    if (host_len) {                                                    // table [samples | frames] per clip
+        std::vector<int32_t>& tab = ctx->vl_host;
+        tab.assign((size_t)2 * B, 0);
+        for (int b = 0; b < B; ++b) {
+            if (host_len[b] <= FE_PAD || host_len[b] > N22 || si_mel_frames(host_len[b]) < 1)
+                return si_fail(ctx, SI_EINVAL, "ragged batch: clip %d holds %d samples: too short for the mel front-end or longer than its row (%d)", b, host_len[b], N22);
+            tab[b] = host_len[b];
+            tab[(size_t)B + b] = si_mel_frames(host_len[b]);
+        }
+        int32_t* d_tab = reinterpret_cast<int32_t*>(W.bytes(tab.size() * 4));
+        if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: mel workspace carve exceeded its own estimate");
+        if ((rc = vl_upload(ctx, d_tab, st))) return rc;
+        d_n = d_tab; d_tm = d_tab + B;
+    }
     if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: mel workspace carve exceeded its own estimate");
     const float* hann = reinterpret_cast<const float*>(ctx->fe_dev + ctx->fe_hann);
-    if (normalize && (rc = si_launch_wave_peak(ctx, wave22, mask_start, mask_end, B, N22, peak, st))) return rc;
-    if ((rc = si_launch_mel_frames(ctx, wave22, mask_start, mask_end, peak, hann, B, N22, Tm, FE_HOP, FE_PAD, FE_NFFT, FE_KC, normalize, frames, st)))
+    if (normalize && (rc = si_launch_wave_peak(ctx, wave22, mask_start, mask_end, B, N22, peak, st, d_n))) return rc;
+    if ((rc = si_launch_mel_frames(ctx, wave22, mask_start, mask_end, peak, hann, B, N22, Tm, FE_HOP, FE_PAD, FE_NFFT, FE_KC, normalize, frames, st, d_n, d_tm)))
         return rc;
     if ((rc = si_tap(ctx, "mel_frames", frames, (long)B * Tm * FE_FRAME, st))) return rc;
     // STFT as two exact-fp32 GEMMs on the folded frames: (B*Tm, 528) x (528, 513) -> re, (B*Tm, 512) x (512, 513) -> im
@@ -1408,7 +1644,7 @@ int si_mel_frontend(si_ctx* ctx, const float* wave22, const int32_t* mask_start,
     }
     return si_launch_mel_project(ctx, spec, FE_LDSPEC, FE_NBIN, FE_IMOFF, reinterpret_cast<const float*>(ctx->fe_dev + ctx->fe_basis),
                                  reinterpret_cast<const int32_t*>(ctx->fe_dev + ctx->fe_lo),
-                                 reinterpret_cast<const int32_t*>(ctx->fe_dev + ctx->fe_hi), FE_NMEL, B, Tm, mel_out, st);
+                                 reinterpret_cast<const int32_t*>(ctx->fe_dev + ctx->fe_hi), FE_NMEL, B, Tm, mel_out, st, d_tm);
 }
 
 }  // extern "C"

@@ -28,6 +28,50 @@ int si_num_cus(si_ctx* ctx);   // compute units of the context's device (persist
 typedef unsigned short bf16_t;   // raw bf16 bits
 
 // ------------------------------------------------------------------------------------------------
+// Ragged batches (BASELINE configs[4]: clips of different lengths in ONE launch, each clip's result equal to that clip run
+// alone -- the reference's one-file-per-run script, I_ea/predict.py:76-207).  Storage keeps a fixed stride per clip (the
+// longest clip's); a device int32 array holds every clip's own row count, and the persistent kernels number their tiles clip
+// by clip WITHOUT gaps: tile t -> (clip, first row, the clip's rows).  `t` is wave-uniform; every lane gets the result.
+// One vector load, a 6-step wave scan and a ballot per call (per tile of tens of microseconds).
+// ------------------------------------------------------------------------------------------------
+struct SiVlTile { int b, row0, L; };
+#ifdef __HIPCC__
+__device__ __forceinline__ SiVlTile si_vl_tile(const int32_t* __restrict__ lens, int B, int step, int t) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    int base = 0;
+    for (int s0 = 0; s0 < B; s0 += 64) {
+        const int s = s0 + lane;
+        const int Lb = s < B ? lens[s] : 0;
+        const int nb = Lb > 0 ? (Lb + step - 1) / step : 0;
+        int incl = nb;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        const int tot = __shfl(incl, 63, 64);
+        if (t < base + tot) {                                          // wave-uniform
+            const unsigned long long m = __ballot(base + incl > t);
+            const int l = (int)__builtin_ctzll(m);
+            SiVlTile r;
+            r.b = s0 + l;
+            r.row0 = (t - base - __shfl(incl - nb, l, 64)) * step;
+            r.L = __shfl(Lb, l, 64);
+            return r;
+        }
+        base += tot;
+    }
+    return SiVlTile{B, 0, 0};                                          // t past the last tile
+}
+#endif
+// the same count on the host: tiles of `step` rows over clips of lens[b] rows
+static inline long si_vl_tiles(const int32_t* lens, int B, int step) {
+    long n = 0;
+    for (int b = 0; b < B; ++b) if (lens[b] > 0) n += (lens[b] + step - 1) / step;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------
 // "Tap GEMM": every contraction of the path (Conv1d with stride/dilation/groups, ConvTranspose1d split
 // into stride phases, Linear) is
 //     out[seg][m][n] = epi( sum_tap sum_ci  pro(x[seg][m*stride + tap*dil - pad][g*Cin + ci]) * W[g][tap][n][ci] )
@@ -65,6 +109,17 @@ struct TapGemmParams {
     double algo_macs;      // algorithmic multiply-accumulates of the layer (0: derive from the GEMM shape)
     int wide_epilogue;     // set by the launcher: row-contiguous 16-byte epilogue through an LDS transpose
     int lingemm;           // caller allows the dedicated bf16 GEMM kernel (lingemm.hip) when the shape fits it
+    // ragged batches (all device int32 (nseg), all NULL for uniform segments): segment s reads seg_lin[s] input rows (instead
+    // of Lin: rows outside read as zero -- the convolution's padding at the clip's OWN end), computes seg_m[s] output rows
+    // (instead of M: tiles past them exit at once) and stores inside [0, seg_orows[s] * olim_mul) (instead of olimit).
+    // seg_row_off: PACKED rows -- segment s starts at row seg_row_off[s] of x (row stride ldx) and of out / res / out16
+    // (row stride ldo) instead of at s * x_seg_stride / s * o_seg_stride.
+    const int32_t* seg_lin;
+    const int32_t* seg_m;
+    const int32_t* seg_orows;
+    int olim_mul;
+    const int32_t* seg_row_off;
+    const int32_t* seg_m_host;   // host copy of seg_m (grid sizing of the kernels that walk tiles without gaps)
 };
 
 // N-tile width the launcher uses for a given N; the packer pads W rows to a multiple of it.
@@ -88,6 +143,9 @@ struct LinGemmParams {
     int act;
     int xcd_rows;                               // set by the launcher: > 0 = XCD-aware tile order over this many row blocks
     int persistent;                             // set by the launcher (gemm256): workgroups walk tiles slot, slot + grid / 8, ... of their XCD's list
+    // ragged batches: segment s holds seg_m[s] output rows (device int32 (nseg); NULL: M for all); seg_m_host = the same on the host
+    const int32_t* seg_m;
+    const int32_t* seg_m_host;
 };
 int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st);
 // The same contract on 256 x 256 tiles with LDS-DMA staging (gemm256.hip), for the shapes whose tiles fill the chip; returns 1 otherwise.
@@ -111,6 +169,8 @@ struct WaveNormParams {           // A0 + A1 (group-norm flavour)
                                   // I_da/src/hubert_feature_reader.py:53-54)
     const double* pre_add;        // (B) or null: value added to every sample BEFORE the zero mask, in fp64, rounded to fp32
                                   // once -- `(y + 1e-6) * mask` on the float64 clip (I_da/scripts/inpainting.py:187-192)
+    const int32_t* seg_L1;        // (B) or null: ragged batches -- conv0 output rows of each clip's OWN length (with valid_len =
+                                  // its samples): GroupNorm statistics over those rows only, rows past them are not written
 };
 
 int si_launch_wave_stats(si_ctx* ctx, const WaveNormParams& p, double* stats /*B*2: mean, rstd*/, hipStream_t st);
@@ -132,11 +192,17 @@ int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const flo
 // out16 (optional): write the result as bf16 there INSTEAD of fp32 into out
 // bf16_products: with out16 given, run both products on bf16 MFMA (fp32 softmax); false keeps the exact-fp32 kernel
 // valid_frames (B) or null: keys >= valid_frames[b] are padding and excluded for every query (modeling_hubert.py:250-251)
+// row_off (B + 1, device) or null: ragged batches on PACKED rows -- clip b = rows [row_off[b], row_off[b + 1]); T is then the
+// longest clip's frame count (grid sizing) and real_t2 = sum of T_b^2 (the algorithmic flop count)
 int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st,
-                        unsigned short* out16 = nullptr, bool bf16_products = true, const int32_t* valid_frames = nullptr);
+                        unsigned short* out16 = nullptr, bool bf16_products = true, const int32_t* valid_frames = nullptr,
+                        const int32_t* row_off = nullptr, double real_t2 = 0.0);
 // bf16 encoder mode: q | k | v arrive as bf16 (B, T, 3H) from the QKV GEMM's epilogue; both products on bf16 MFMA
 int si_launch_attention_bf16in(si_ctx* ctx, const unsigned short* qkv16, int B, int T, int H, int heads, hipStream_t st,
-                               unsigned short* out16, const int32_t* valid_frames = nullptr);
+                               unsigned short* out16, const int32_t* valid_frames = nullptr, const int32_t* row_off = nullptr,
+                               double real_t2 = 0.0);
+// ragged batches: (B, Tmax, C) padded rows <-> packed rows [row_off[b], row_off[b + 1]); unpack zeroes the padded rows
+int si_launch_repack_rows(si_ctx* ctx, const float* src, float* dst, int B, int Tmax, int C, const int32_t* row_off, bool unpack, hipStream_t st);
 // valid_frames[b] = conv-stack length of valid_len[b] samples (modeling_hubert.py:664-677), clamped to [1, T]
 int si_launch_frame_lengths(si_ctx* ctx, const int32_t* valid_len, int B, int nconv, const int32_t* kernels, const int32_t* strides,
                             int T, int32_t* valid_frames, hipStream_t st);
@@ -146,7 +212,8 @@ int si_launch_zero_padded_rows(si_ctx* ctx, float* x, int B, int T, int H, const
 // cosine arg-max against centred centroids + splice of the raw centroid into mel (A10..A13)
 int si_launch_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,
                               const float* cb_centered /*K x D*/, const float* cb_raw /*K x D*/,
-                              const float* cb_rnorm /*K*/, int K, float* mel, int Tm, int64_t* labels, hipStream_t st);
+                              const float* cb_rnorm /*K*/, int K, float* mel, int Tm, int64_t* labels, hipStream_t st,
+                              const int32_t* frame_cnt = nullptr /* (B): frames replaced per clip (ragged batches), <= Lm */);
 
 // out[b][t] = (t < first[b] || t >= last[b]) ? clean[b][t] : masked[b][t]  (I_da/scripts/inpainting.py:209-214)
 int si_launch_code_splice(si_ctx* ctx, const int64_t* clean, const int64_t* masked, const int32_t* first, const int32_t* last, int B, int T,
@@ -173,17 +240,18 @@ int si_launch_sisdr(si_ctx* ctx, const float* est, const float* ref, int B, int 
 // ------------------------------------------------------------------------------------------------
 // mel front-end kernels (frontend_kernels.hip)
 // ------------------------------------------------------------------------------------------------
+// n_len / tm_len (B, device) or null: ragged batches -- clip b holds n_len[b] samples (row stride N) and tm_len[b] frames (stride Tm)
 int si_launch_wave_peak(si_ctx* ctx, const float* wav, const int32_t* ms, const int32_t* me, int B, int N, float* peak,
-                        hipStream_t st);
+                        hipStream_t st, const int32_t* n_len = nullptr);
 // mask -> normalise*0.95 -> reflect-pad -> Hann window, as the (B*Tm, kc + nfft / 2) matrix of FOLDED frames
 // [w[0], w[k] + w[nfft - k] (k = 1 .. nfft/2 - 1), w[nfft/2], zeros up to kc | 0, w[k] - w[nfft - k]]: the operands of the two
 // half-size DFT GEMMs (cosine / sine part)
 int si_launch_mel_frames(si_ctx* ctx, const float* wav, const int32_t* ms, const int32_t* me, const float* peak,
                          const float* hann, int B, int N, int Tm, int hop, int pad, int nfft, int kc, int normalize, float* frames,
-                         hipStream_t st);
+                         hipStream_t st, const int32_t* n_len = nullptr, const int32_t* tm_len = nullptr);
 // spec rows [re | pad | im at im_off] -> sqrt(re^2+im^2+1e-9) -> banded mel basis -> log(clamp 1e-5) -> mel (B, nmel, Tm)
 int si_launch_mel_project(si_ctx* ctx, const float* spec, int ld_spec, int nbin, int im_off, const float* basis_t, const int32_t* lo,
-                          const int32_t* hi, int nmel, int B, int Tm, float* mel, hipStream_t st);
+                          const int32_t* hi, int nmel, int B, int Tm, float* mel, hipStream_t st, const int32_t* tm_len = nullptr);
 
 // polyphase FIR resampler (upfirdn with resample_poly's centring); taps are device fp32, already pre-padded
 int si_launch_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const float* taps, int ntaps, int up, int down,
@@ -225,6 +293,10 @@ struct UpsampleParams {
     int Cin, N, taps;
     long ooff;                        // GEMM element (m, n) is element m * N + n - ooff of its clip's output (ooff = padding * Cout)
     long o_clip_stride, o_clip_elems; // elements between clips / per clip of the output
+    // ragged batches (NULL: uniform): clip b holds lens_lin[b] input rows, lens_m[b] GEMM rows and lens_lin[b] * N output elements
+    // (k = 2 * stride: N output elements per input row); *_host: the same on the host; Lin / M / o_clip_elems = the longest clip's
+    const int32_t* lens_lin; const int32_t* lens_m; const int32_t* lens_m_host;
+    int total_tiles;                  // set by the launcher
 };
 // SI_OK when launched, negative on error, 1 when the shape is not covered (the caller runs the tap-GEMM)
 int si_launch_upsample_stream(si_ctx* ctx, const UpsampleParams& p, hipStream_t st);
@@ -241,6 +313,9 @@ struct ResPairParams {
     int B, L, k, dil;
     float alpha;                 // out = (conv2 + b2 + y) * alpha
     int accumulate;              // out += previous out16
+    // ragged batches (NULL: every clip holds L rows): clip b holds lens[b] rows at stride L; lens_host = the same on the host
+    const int32_t* lens; const int32_t* lens_host;
+    int total_tiles;             // set by the launcher
 };
 int si_launch_respair_wide(si_ctx* ctx, int C, const ResPairParams& p, hipStream_t st);
 // A whole ResBlock1 -- three (c1, c2) pairs chained, the residual stream kept in LDS -- as one kernel (reschain.hip: C = 32).
@@ -256,23 +331,29 @@ struct ResChainParams {
     int dil[3];                  // dilation of c1 per pair (c2 has dilation 1)
     float alpha;
     int accumulate;
+    const int32_t* lens; const int32_t* lens_host;   // ragged batches: as ResPairParams
+    int total_tiles;
 };
 int si_launch_reschain(si_ctx* ctx, int C, const ResChainParams& p, hipStream_t st);
 int si_launch_respair(si_ctx* ctx, int C, const unsigned short* y16, unsigned short* out16, const void* w1, const void* w2,
-                      const float* b1, const float* b2, int B, int L, int k, int dil, float alpha, int accumulate, hipStream_t st);
+                      const float* b1, const float* b2, int B, int L, int k, int dil, float alpha, int accumulate, hipStream_t st,
+                      const int32_t* lens = nullptr, const int32_t* lens_host = nullptr);
 
 // ------------------------------------------------------------------------------------------------
 // vocoder kernels (vocoder_kernels.hip)
 // ------------------------------------------------------------------------------------------------
 // mel (B, D, Tm) channels-first -> (B, Tout, ldo) channels-last, time-stretched (stretch=1) or copied;
 // channels D..ldo-1 are written as zero.
+// tm_len / tout_len (B, device) or null: ragged batches -- clip b holds tm_len[b] mel frames (stride Tm) and tout_len[b] output rows (stride Tout)
 int si_launch_extend_mel(si_ctx* ctx, const float* mel, int B, int D, int Tm, int Tout, int stretch, float* out, int ldo,
-                         hipStream_t st);
+                         hipStream_t st, const int32_t* tm_len = nullptr, const int32_t* tout_len = nullptr);
 // I_da CodeGenerator front (f-2): embedding look-ups + frame repeat + channel concat -> (B, nparts * E, F) channels-first
 int si_launch_small_conv1d(si_ctx* ctx, const float* x, const float* w, const float* bias, const float* res, float* y, int B, int Cin,
                            int Tin, int Cout, int Tout, int K, int stride, int dil, int pad, int relu_in, int channels_last, hipStream_t st);
 int si_launch_unit_frontend(si_ctx* ctx, const int64_t* code, int Fc, const int64_t* f0_code, int Fp, const float* spk_emb,
                             const float* emb_c, int Kc, const float* emb_p, int Kp, int E, int B, float* out, hipStream_t st);
 // leaky_relu(0.01) -> Conv1d(C -> 1, k, pad k/2) -> tanh ; x (B, L, C) channels-last -> wav (B, L)
+// lens / lens_host (B) or null: ragged batches -- clip b holds lens[b] rows (stride L) and as many output samples (stride L)
 int si_launch_conv_post(si_ctx* ctx, const float* x, const float* w /*[k][C]*/, const float* bias, int B, int L, int C, int k,
-                        float* wav, hipStream_t st, const unsigned short* x16 = nullptr /* raw fp16 input instead of x */);
+                        float* wav, hipStream_t st, const unsigned short* x16 = nullptr /* raw fp16 input instead of x */,
+                        const int32_t* lens = nullptr, const int32_t* lens_host = nullptr);

@@ -15,6 +15,7 @@
 //    round trip, no shuffles; cdna_hip_programming.md section 3 "An accumulator tile as the next MFMA's operand").
 //  * codebook_splice : cosine arg-max against centred centroids + raw-centroid splice (I_ea/loss_fn.py:44-47,
 //    I_ea/predict.py:164-168,184-187).
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -107,9 +108,14 @@ __global__ __launch_bounds__(256) void conv0_lagsums_kernel(WaveNormParams p, co
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int nchunks = gridDim.x;
     const int t0 = chunk * SI_C0_TCH;
-    const int nt = min(SI_C0_TCH, p.L1 - t0);
+    const int L1 = p.seg_L1 ? p.seg_L1[b] : p.L1;                     // ragged batches: the clip's own conv0 rows
+    const int nt = min(SI_C0_TCH, L1 - t0);
     const int K = p.K, S = p.S;
     const int NP = K + K * (K + 1) / 2;
+    if (nt <= 0) {                                                    // a chunk past the clip: exact zeros keep the fixed-order sum
+        if ((int)threadIdx.x < NP) partials[((long)b * nchunks + chunk) * NP + threadIdx.x] = 0.0;   // equal to the clip's own
+        return;
+    }
     const float mean = (float)stats[2 * b], rstd = (float)stats[2 * b + 1];
     const int ms = p.mask_start ? p.mask_start[b] : 0, ml = p.mask_len ? p.mask_len[b] : 0;
     const float* x = p.wav + (long)b * p.N;
@@ -161,8 +167,9 @@ __global__ __launch_bounds__(256) void conv0_gn_affine_kernel(WaveNormParams p, 
         for (int k0 = 0; k0 < K; ++k0)
             for (int k1 = k0; k1 < K; ++k1, ++q)
                 e2 += (k0 == k1 ? 1.0 : 2.0) * (double)wc[k0] * (double)wc[k1] * tot[q];
-        m /= p.L1;
-        double var = e2 / p.L1 - m * m;
+        const int L1 = p.seg_L1 ? p.seg_L1[b] : p.L1;
+        m /= L1;
+        double var = e2 / L1 - m * m;
         if (var < 0) var = 0;
         const double rstd = 1.0 / sqrt(var + 1e-5);
         const double a = (double)gamma[c] * rstd;
@@ -188,7 +195,8 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(WaveNormParams p, cons
     float* xs = reinterpret_cast<float*>(smem);
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * SI_C0_ROWS;
-    const int nt = min(SI_C0_ROWS, p.L1 - t0);
+    const int nt = min(SI_C0_ROWS, (p.seg_L1 ? p.seg_L1[b] : p.L1) - t0);
+    if (nt <= 0) return;                                              // ragged batches: rows past the clip's own are not written
     const int S = p.S, C = p.C;
     const float mean = (float)stats[2 * b], rstd = (float)stats[2 * b + 1];
     const int ms = p.mask_start ? p.mask_start[b] : 0, ml = p.mask_len ? p.mask_len[b] : 0;
@@ -330,6 +338,34 @@ int si_launch_zero_padded_rows(si_ctx* ctx, float* x, int B, int T, int H, const
     return SI_OK;
 }
 
+// ragged batches: rows of clip b, [0, T_b) of a (B, Tmax, C) padded tensor <-> rows [row_off[b], row_off[b + 1]) of a packed one.
+// UNPACK also zeroes the padded rows [T_b, Tmax) of the destination (the output is defined on all of it).
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void repack_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int Tmax, int C,
+                                                          const int32_t* __restrict__ row_off) {
+    const int b = blockIdx.y;
+    const int r0 = row_off[b], Tb = row_off[b + 1] - r0;
+    const int c4n = C / 4;
+    for (int t = blockIdx.x; t < (UNPACK ? Tmax : Tb); t += gridDim.x) {
+        const long pad = ((long)b * Tmax + t) * C, pk = ((long)r0 + t) * C;
+        for (int i = threadIdx.x; i < c4n; i += 256) {
+            if (UNPACK) *reinterpret_cast<f32x4*>(dst + pad + 4 * i) = t < Tb ? *reinterpret_cast<const f32x4*>(src + pk + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            else *reinterpret_cast<f32x4*>(dst + pk + 4 * i) = *reinterpret_cast<const f32x4*>(src + pad + 4 * i);
+        }
+    }
+}
+int si_launch_repack_rows(si_ctx* ctx, const float* src, float* dst, int B, int Tmax, int C, const int32_t* row_off, bool unpack, hipStream_t st) {
+    if (C % 4) return si_fail(ctx, SI_EINVAL, "repack_rows: width %d must be a multiple of 4", C);
+    if (B <= 0 || Tmax <= 0) return SI_OK;
+    dim3 grid((unsigned)std::min(Tmax, 512), B);
+    si_prof_begin(ctx, unpack ? "unpack_rows" : "pack_rows", 0.0, 8.0 * B * Tmax * C, st);
+    if (unpack) hipLaunchKernelGGL(repack_rows_kernel<true>, grid, dim3(256), 0, st, src, dst, Tmax, C, row_off);
+    else hipLaunchKernelGGL(repack_rows_kernel<false>, grid, dim3(256), 0, st, src, dst, Tmax, C, row_off);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // One wave per row at a time, C % 4 == 0, C <= 2048 (the row lives in 8 float4 registers per lane).  Waves are
 // persistent: wave w walks rows w, w + W, ... and requests its next row before it reduces the current one, so the reads
@@ -431,9 +467,12 @@ int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const flo
 #define ATT_KT 32
 #define ATT_LD 68     // 64 + 4 floats: 16-B aligned rows, consecutive rows shift by 4 banks
 
+// row_off (B + 1) or null: ragged batches, PACKED rows -- clip b is rows [row_off[b], row_off[b + 1]) of qkv / out and its
+// frame count is their difference (instead of b * T ... and T); the grid covers the longest clip, blocks past a clip exit.
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                         unsigned short* __restrict__ out16, int T, int H,
-                                                        int heads, const int32_t* __restrict__ valid_frames) {
+                                                        int heads, const int32_t* __restrict__ valid_frames,
+                                                        const int32_t* __restrict__ row_off) {
     __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_LD];
     __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * ATT_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -441,7 +480,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
     const int q0 = blockIdx.x * 128 + wave * 32;
     const long ld = 3L * H;
-    const float* base = qkv + (long)b * T * ld + h * 64;
+    const long row0 = row_off ? row_off[b] : (long)b * T;
+    if (row_off) { T = row_off[b + 1] - row_off[b]; if ((int)blockIdx.x * 128 >= T) return; }
+    const float* base = qkv + row0 * ld + h * 64;
     const int Tk = valid_frames ? min(max(valid_frames[b], 1), T) : T;   // keys beyond it are padding (every query row still runs)
 
     // this lane's half of its query row, pre-scaled by head_dim^-0.5 = 2^-3 (exact)
@@ -523,7 +564,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const int q = q0 + l31;
     if (q < T) {
         const float inv = 1.0f / lrun;
-        const long o = ((long)b * T + q) * H + h * 64;
+        const long o = (row0 + q) * H + h * 64;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int d = 8 * g4 + 4 * half;
@@ -550,7 +591,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __restrict__ qkv, unsigned short* __restrict__ out16, int T,
-                                                             int H, int heads, const int32_t* __restrict__ valid_frames) {
+                                                             int H, int heads, const int32_t* __restrict__ valid_frames,
+                                                             const int32_t* __restrict__ row_off) {
     __shared__ __attribute__((aligned(16))) unsigned short Ks[ATT_KT * ATB_LDK];
     __shared__ __attribute__((aligned(16))) unsigned short Vt[64 * ATB_LDV];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -558,7 +600,9 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __rest
     const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
     const int q0 = blockIdx.x * 128 + wave * 32;
     const long ld = 3L * H;
-    const float* base = qkv + (long)b * T * ld + h * 64;
+    const long row0 = row_off ? row_off[b] : (long)b * T;
+    if (row_off) { T = row_off[b + 1] - row_off[b]; if ((int)blockIdx.x * 128 >= T) return; }
+    const float* base = qkv + row0 * ld + h * 64;
     const int Tk = valid_frames ? min(max(valid_frames[b], 1), T) : T;
 
     bf16x8 qb[4];                                          // query row, 8 dims per k-step and lane half, scaled by 2^-3
@@ -651,7 +695,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __rest
     const int q = q0 + l31;
     if (q < T) {
         const float inv = 1.0f / lrun;
-        const long o = ((long)b * T + q) * H + h * 64;
+        const long o = (row0 + q) * H + h * 64;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int d = 8 * g4 + 4 * half;
@@ -667,7 +711,8 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const float* __rest
 // applied to the fp32 matrix, moved into the producer -- bit-identical scores, half the bytes written and read).  The
 // 2^-3 query scale is exact in bf16.
 __global__ __launch_bounds__(256) void attention_bf16in_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out16, int T,
-                                                               int H, int heads, const int32_t* __restrict__ valid_frames) {
+                                                               int H, int heads, const int32_t* __restrict__ valid_frames,
+                                                               const int32_t* __restrict__ row_off) {
     __shared__ __attribute__((aligned(16))) unsigned short Ks[ATT_KT * ATB_LDK];
     __shared__ __attribute__((aligned(16))) unsigned short Vt[64 * ATB_LDV];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -675,7 +720,9 @@ __global__ __launch_bounds__(256) void attention_bf16in_kernel(const unsigned sh
     const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
     const int q0 = blockIdx.x * 128 + wave * 32;
     const long ld = 3L * H;
-    const unsigned short* base = qkv + (long)b * T * ld + h * 64;
+    const long row0 = row_off ? row_off[b] : (long)b * T;
+    if (row_off) { T = row_off[b + 1] - row_off[b]; if ((int)blockIdx.x * 128 >= T) return; }
+    const unsigned short* base = qkv + row0 * ld + h * 64;
     const int Tk = valid_frames ? min(max(valid_frames[b], 1), T) : T;
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
@@ -770,7 +817,7 @@ __global__ __launch_bounds__(256) void attention_bf16in_kernel(const unsigned sh
     const int q = q0 + l31;
     if (q < T) {
         const float inv = 1.0f / lrun;
-        const long o = ((long)b * T + q) * H + h * 64;
+        const long o = (row0 + q) * H + h * 64;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int d = 8 * g4 + 4 * half;
@@ -788,7 +835,8 @@ __global__ __launch_bounds__(256) void attention_bf16in_kernel(const unsigned sh
 // kernel's, statement for statement: bit-identical output.  LDS: per key tile a [32][ATB_LDK] block of K and a [64][ATB_LDV]
 // block of V^T (the tiled kernel's layouts): 9 216 bytes per tile, 64.5 KB at T = 199 -- two workgroups per CU.
 __global__ __launch_bounds__(512) void attention_bf16in_whole_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out16, int T,
-                                                                     int H, int heads, const int32_t* __restrict__ valid_frames) {
+                                                                     int H, int heads, const int32_t* __restrict__ valid_frames,
+                                                                     const int32_t* __restrict__ row_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned short att_smem[];
     const int nkt = (int)(blockDim.x >> 6);                            // key tiles == waves == ceil(T / 32)
     unsigned short* const Ks = att_smem;                               // [nkt][32][ATB_LDK]
@@ -798,7 +846,9 @@ __global__ __launch_bounds__(512) void attention_bf16in_whole_kernel(const unsig
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
     const int q0 = wave * 32;
     const long ld = 3L * H;
-    const unsigned short* base = qkv + (long)b * T * ld + h * 64;
+    const long row0 = row_off ? row_off[b] : (long)b * T;
+    if (row_off) T = row_off[b + 1] - row_off[b];                      // (every wave stays: they all stage K / V; waves past the clip store nothing)
+    const unsigned short* base = qkv + row0 * ld + h * 64;
     const int Tk = valid_frames ? min(max(valid_frames[b], 1), T) : T;
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
@@ -897,7 +947,7 @@ __global__ __launch_bounds__(512) void attention_bf16in_whole_kernel(const unsig
     const int q = q0 + l31;
     if (q < T) {
         const float inv = 1.0f / lrun;
-        const long o = ((long)b * T + q) * H + h * 64;
+        const long o = (row0 + q) * H + h * 64;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int d = 8 * g4 + 4 * half;
@@ -910,32 +960,33 @@ __global__ __launch_bounds__(512) void attention_bf16in_whole_kernel(const unsig
 }
 
 int si_launch_attention_bf16in(si_ctx* ctx, const unsigned short* qkv16, int B, int T, int H, int heads, hipStream_t st, unsigned short* out16,
-                               const int32_t* valid_frames) {
+                               const int32_t* valid_frames, const int32_t* row_off, double real_t2) {
     if (heads <= 0 || H != heads * 64) return si_fail(ctx, SI_EINVAL, "attention kernel needs head_dim 64 (H=%d heads=%d)", H, heads);
     if (B <= 0 || T <= 0) return SI_OK;
     dim3 grid((T + 127) / 128, B * heads);
-    si_prof_begin(ctx, "attention_bf16", 4.0 * B * (double)T * T * H, 8.0 * B * T * H, st);
+    const int nkt = (T + ATT_KT - 1) / ATT_KT;
+    const size_t lds = (size_t)nkt * (ATT_KT * ATB_LDK + 64 * ATB_LDV) * sizeof(unsigned short);
+    if (T <= 256) if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(attention_bf16in_whole_kernel), lds)) return rc;   // (before the profile bracket opens)
+    // (ragged batches: T = the longest clip; real_t2 = sum of T_b^2 for the algorithmic count)
+    si_prof_begin(ctx, "attention_bf16", 4.0 * (real_t2 > 0 ? real_t2 : B * (double)T * T) * H, 8.0 * B * T * H, st);
     if (T <= 256) {                                                    // the whole clip's K / V in LDS, one workgroup per (clip, head)
-        const int nkt = (T + ATT_KT - 1) / ATT_KT;
-        const size_t lds = (size_t)nkt * (ATT_KT * ATB_LDK + 64 * ATB_LDV) * sizeof(unsigned short);
-        if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(attention_bf16in_whole_kernel), lds)) return rc;
-        hipLaunchKernelGGL(attention_bf16in_whole_kernel, dim3(B * heads), dim3(64 * nkt), lds, st, qkv16, out16, T, H, heads, valid_frames);
+        hipLaunchKernelGGL(attention_bf16in_whole_kernel, dim3(B * heads), dim3(64 * nkt), lds, st, qkv16, out16, T, H, heads, valid_frames, row_off);
     } else
-    hipLaunchKernelGGL(attention_bf16in_kernel, grid, dim3(256), 0, st, qkv16, out16, T, H, heads, valid_frames);
+    hipLaunchKernelGGL(attention_bf16in_kernel, grid, dim3(256), 0, st, qkv16, out16, T, H, heads, valid_frames, row_off);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
 }
 
 int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T, int H, int heads, hipStream_t st,
-                        unsigned short* out16, bool att_bf16, const int32_t* valid_frames) {
+                        unsigned short* out16, bool att_bf16, const int32_t* valid_frames, const int32_t* row_off, double real_t2) {
     if (heads <= 0 || H != heads * 64) return si_fail(ctx, SI_EINVAL, "attention kernel needs head_dim 64 (H=%d heads=%d)", H, heads);
     if (B <= 0 || T <= 0) return SI_OK;
     dim3 grid((T + 127) / 128, B * heads);
     // bf16 encoder mode (out16 given): the bf16-MFMA form; SI_ATT_BF16=0 at context creation keeps the exact-fp32 kernel
-    si_prof_begin(ctx, (out16 && att_bf16) ? "attention_bf16" : "attention_f32", 4.0 * B * (double)T * T * H, 16.0 * B * T * H, st);   // 2*T^2*H MACs
-    if (out16 && att_bf16) hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, st, qkv, out16, T, H, heads, valid_frames);
-    else hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, qkv, out, out16, T, H, heads, valid_frames);
+    si_prof_begin(ctx, (out16 && att_bf16) ? "attention_bf16" : "attention_f32", 4.0 * (real_t2 > 0 ? real_t2 : B * (double)T * T) * H, 16.0 * B * T * H, st);   // 2*T^2*H MACs
+    if (out16 && att_bf16) hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, st, qkv, out16, T, H, heads, valid_frames, row_off);
+    else hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, st, qkv, out, out16, T, H, heads, valid_frames, row_off);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
@@ -976,17 +1027,18 @@ __device__ __forceinline__ int codebook_argmax_128(const float* v, int D, const 
 }
 
 // One workgroup per (clip, masked frame).  D <= 128.
+// frame_cnt (B) or null: ragged batches -- clip b replaces frame_cnt[b] frames (blind mode: all of ITS frames); j past it is label -1
 __global__ __launch_bounds__(128) void codebook_splice_kernel(const float* __restrict__ feats, int T, int D,
                                                               const int32_t* __restrict__ frame_pos, int Lm,
                                                               const float* __restrict__ cc, const float* __restrict__ raw,
                                                               const float* __restrict__ rnorm, int K, float* __restrict__ mel,
-                                                              int Tm, int64_t* __restrict__ labels) {
+                                                              int Tm, int64_t* __restrict__ labels, const int32_t* __restrict__ frame_cnt) {
     __shared__ float v[128];
     __shared__ float bs[2];
     __shared__ int bi[2];
     const int b = blockIdx.y, j = blockIdx.x;
     const int pos = frame_pos[b] + j;
-    if (pos < 0 || pos >= T) {                                       // uniform per block: no such encoder frame
+    if (pos < 0 || pos >= T || (frame_cnt && j >= frame_cnt[b])) {   // uniform per block: no such encoder frame
         if (threadIdx.x == 0 && labels) labels[(long)b * Lm + j] = -1;
         return;
     }
@@ -1176,12 +1228,12 @@ int si_launch_codebook_gather(si_ctx* ctx, const int64_t* labels, int B, int D, 
 
 int si_launch_codebook_splice(si_ctx* ctx, const float* feats, int B, int T, int D, const int32_t* frame_pos, int Lm,
                               const float* cb_centered, const float* cb_raw, const float* cb_rnorm, int K, float* mel, int Tm,
-                              int64_t* labels, hipStream_t st) {
+                              int64_t* labels, hipStream_t st, const int32_t* frame_cnt) {
     if (D > 128) return si_fail(ctx, SI_EINVAL, "codebook dim %d > 128", D);
     if (B <= 0 || Lm <= 0) return SI_OK;
     si_prof_begin(ctx, "codebook_splice", 2.0 * B * Lm * (double)K * D, 4.0 * B * Lm * 2.0 * D, st);
     hipLaunchKernelGGL(codebook_splice_kernel, dim3(Lm, B), dim3(128), 0, st, feats, T, D, frame_pos, Lm, cb_centered, cb_raw,
-                       cb_rnorm, K, mel, Tm, labels);
+                       cb_rnorm, K, mel, Tm, labels, frame_cnt);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

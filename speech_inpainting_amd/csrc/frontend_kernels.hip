@@ -15,15 +15,18 @@
 //                       store into the reference's (B, 80, Tm) layout
 #include "common.h"
 
+// n_len (B) or null: ragged batches -- clip b holds n_len[b] samples inside its row of Ns
 __global__ __launch_bounds__(1024) void wave_peak_kernel(const float* __restrict__ wav, const int32_t* __restrict__ ms,
-                                                         const int32_t* __restrict__ me, int N, float* __restrict__ peak) {
+                                                         const int32_t* __restrict__ me, int Ns, float* __restrict__ peak,
+                                                         const int32_t* __restrict__ n_len) {
     const int b = blockIdx.x;
-    const float* x = wav + (size_t)b * N;
+    const float* x = wav + (size_t)b * Ns;
+    const int N = n_len ? n_len[b] : Ns;
     const int s = ms ? ms[b] : 0, e = ms ? me[b] : 0;
     float m = 0.f;
     // 16 bytes per lane, four loads in flight (one workgroup walks a whole clip); scalar loop for the tail / unaligned clips
-    const bool vec = (N & 3) == 0 && (reinterpret_cast<size_t>(wav) & 15) == 0;
-    const int n4 = vec ? N : 0;
+    const bool vec = (Ns & 3) == 0 && (reinterpret_cast<size_t>(wav) & 15) == 0;
+    const int n4 = vec ? (N & ~3) : 0;
 #pragma unroll 4
     for (int i = threadIdx.x * 4; i < n4; i += 1024 * 4) {
         const float4 q = *reinterpret_cast<const float4*>(x + i);
@@ -47,12 +50,17 @@ __global__ __launch_bounds__(1024) void wave_peak_kernel(const float* __restrict
 
 // grid (Tm, B), 256 threads.  The windowed frame w[k] = x[.] * hann[k] is written FOLDED for the two half-size DFT GEMMs (api.hip):
 // [ s_0 .. s_{n/2} | zeros up to kc | 0, d_1 .. d_{n/2-1} ],  s_k = w[k] + w[n - k], d_k = w[k] - w[n - k]  (s_0 = w[0], s_{n/2} = w[n/2]).
+// n_len / tm_len (B) or null: ragged batches -- clip b holds n_len[b] samples (row stride Ns; the reflection is at ITS end) and
+// tm_len[b] frames (frame-matrix stride Tm); frames past them are not written
 __global__ __launch_bounds__(256) void mel_frames_kernel(const float* __restrict__ wav, const int32_t* __restrict__ ms,
                                                          const int32_t* __restrict__ me, const float* __restrict__ peak,
-                                                         const float* __restrict__ hann, int N, int Tm, int hop, int pad,
-                                                         int nfft, int kc, int normalize, float* __restrict__ frames) {
+                                                         const float* __restrict__ hann, int Ns, int Tm, int hop, int pad,
+                                                         int nfft, int kc, int normalize, float* __restrict__ frames,
+                                                         const int32_t* __restrict__ n_len, const int32_t* __restrict__ tm_len) {
     const int m = blockIdx.x, b = blockIdx.y;
-    const float* x = wav + (size_t)b * N;
+    if (tm_len && m >= tm_len[b]) return;
+    const float* x = wav + (size_t)b * Ns;
+    const int N = n_len ? n_len[b] : Ns;
     const int s = ms ? ms[b] : 0, e = ms ? me[b] : 0;
     // librosa.util.normalize: divide by max |x|; a peak below the smallest normal float leaves the clip unscaled
     const float pk = normalize ? peak[b] : 1.f;
@@ -87,9 +95,13 @@ __global__ __launch_bounds__(256) void mel_frames_kernel(const float* __restrict
 __global__ __launch_bounds__(128) void mel_project_kernel(const float* __restrict__ spec, int ld_spec, int nbin,
                                                           const float* __restrict__ basis_t, const int32_t* __restrict__ lo,
                                                           const int32_t* __restrict__ hi, int nmel, int Tm, int im_off,
-                                                          float* __restrict__ mel) {
+                                                          float* __restrict__ mel, const int32_t* __restrict__ tm_len) {
     extern __shared__ float mag[];
     const long row = blockIdx.x;
+    if (tm_len && (int)(row % Tm) >= tm_len[row / Tm]) {               // ragged batches: a frame past the clip's own is written as zero
+        for (int i = threadIdx.x; i < nmel; i += blockDim.x) mel[((size_t)(row / Tm) * nmel + i) * Tm + row % Tm] = 0.f;
+        return;
+    }
     const float* sp = spec + row * ld_spec;
     for (int f = threadIdx.x; f < nbin; f += blockDim.x) {
         const float re = sp[f], im = sp[im_off + f];
@@ -105,9 +117,9 @@ __global__ __launch_bounds__(128) void mel_project_kernel(const float* __restric
 }
 
 int si_launch_wave_peak(si_ctx* ctx, const float* wav, const int32_t* ms, const int32_t* me, int B, int N, float* peak,
-                        hipStream_t st) {
+                        hipStream_t st, const int32_t* n_len) {
     si_prof_begin(ctx, "wave_peak", (double)B * N, (double)B * N * 4, st);
-    wave_peak_kernel<<<B, 1024, 0, st>>>(wav, ms, me, N, peak);
+    wave_peak_kernel<<<B, 1024, 0, st>>>(wav, ms, me, N, peak, n_len);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
@@ -115,21 +127,21 @@ int si_launch_wave_peak(si_ctx* ctx, const float* wav, const int32_t* ms, const 
 
 int si_launch_mel_frames(si_ctx* ctx, const float* wav, const int32_t* ms, const int32_t* me, const float* peak,
                          const float* hann, int B, int N, int Tm, int hop, int pad, int nfft, int kc, int normalize, float* frames,
-                         hipStream_t st) {
+                         hipStream_t st, const int32_t* n_len, const int32_t* tm_len) {
     if (nfft % 8 || kc % 4 || kc <= nfft / 2) return si_fail(ctx, SI_EINVAL, "mel_frames: n_fft %d / folded width %d unsupported", nfft, kc);
     if (N <= pad) return si_fail(ctx, SI_EINVAL, "mel_frames: clip of %d samples is not longer than the reflect pad %d", N, pad);
     si_prof_begin(ctx, "mel_frames", 3.0 * B * Tm * nfft, (double)B * N * 4 + (double)B * Tm * nfft * 4, st);
-    mel_frames_kernel<<<dim3(Tm, B), 256, 0, st>>>(wav, ms, me, peak, hann, N, Tm, hop, pad, nfft, kc, normalize, frames);
+    mel_frames_kernel<<<dim3(Tm, B), 256, 0, st>>>(wav, ms, me, peak, hann, N, Tm, hop, pad, nfft, kc, normalize, frames, n_len, tm_len);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
 }
 
 int si_launch_mel_project(si_ctx* ctx, const float* spec, int ld_spec, int nbin, int im_off, const float* basis_t, const int32_t* lo,
-                          const int32_t* hi, int nmel, int B, int Tm, float* mel, hipStream_t st) {
+                          const int32_t* hi, int nmel, int B, int Tm, float* mel, hipStream_t st, const int32_t* tm_len) {
     const long rows = (long)B * Tm;
     si_prof_begin(ctx, "mel_project", (double)rows * (4.0 * nbin + 2.0 * nbin * 2), (double)rows * (2.0 * nbin + nmel) * 4, st);
-    mel_project_kernel<<<(unsigned)rows, 128, (size_t)nbin * sizeof(float), st>>>(spec, ld_spec, nbin, basis_t, lo, hi, nmel, Tm, im_off, mel);
+    mel_project_kernel<<<(unsigned)rows, 128, (size_t)nbin * sizeof(float), st>>>(spec, ld_spec, nbin, basis_t, lo, hi, nmel, Tm, im_off, mel, tm_len);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

@@ -93,15 +93,20 @@ __global__ __launch_bounds__(G_NT, 2) void gemm256_kernel(const LinGemmParams p)
     // p.persistent = 0: the workgroup stops after its first tile.
     const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slot_step = gridDim.x >> 3;
     const int run0 = (int)((long)p.xcd_rows * xcd / 8), run1 = (int)((long)p.xcd_rows * (xcd + 1) / 8);
-    struct TileRef { int seg, m0, n0; bool valid; };
+    struct TileRef { int seg, m0, n0, M; bool valid; };
     auto decode = [&](int it) {
-        TileRef r{0, 0, 0, false};
+        TileRef r{0, 0, 0, p.M, false};
         if (it > 0 && !p.persistent) return r;
         const int tile = run0 + slot0 + it * slot_step;
         if (tile >= run1) return r;
         const int mtx = tile / ntn;
-        r.seg = mtx / mtiles;
-        r.m0 = (mtx - r.seg * mtiles) * G_BM;
+        if (p.seg_m) {                                                 // ragged batches: row blocks numbered segment by segment without gaps
+            const SiVlTile v = si_vl_tile(p.seg_m, p.nseg, G_BM, mtx);
+            r.seg = v.b; r.m0 = v.row0; r.M = v.L;
+        } else {
+            r.seg = mtx / mtiles;
+            r.m0 = (mtx - r.seg * mtiles) * G_BM;
+        }
         r.n0 = (tile - mtx * ntn) * G_BN;
         r.valid = true;
         return r;
@@ -258,8 +263,8 @@ __global__ __launch_bounds__(G_NT, 2) void gemm256_kernel(const LinGemmParams p)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = cur.m0 + wr * 128 + 16 * i + r16;
-            const bool live = m < p.M;
-            const long orow = obase + (long)(live ? m : p.M - 1) * p.ldo + ncol0;    // dead rows read row M - 1 and store nothing
+            const bool live = m < cur.M;
+            const long orow = obase + (long)(live ? m : cur.M - 1) * p.ldo + ncol0;  // dead rows read row M - 1 and store nothing
             f32x4 rv[4];
             if (has_res) {
 #pragma unroll
@@ -308,23 +313,28 @@ int si_launch_gemm256(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     if (p.x_bytes <= 0 || p.w_bytes <= 0 || (long)p.nseg * p.x_seg_stride * 2 + (long)(p.M + 256) * p.lda * 2 >= (1L << 31)) return 1;
     if ((long)(p.N + 256) * p.Cin * 2 + (long)p.ntaps * p.w_tap_stride * 2 >= (1L << 31)) return 1;
     const int mtiles = (p.M + G_BM - 1) / G_BM;
+    const long row_blocks = p.seg_m_host ? si_vl_tiles(p.seg_m_host, p.nseg, G_BM) : (long)p.nseg * mtiles;   // ragged batches: no gaps
+    double rows_real = (double)p.nseg * p.M;
+    if (p.seg_m_host) { rows_real = 0; for (int s = 0; s < p.nseg; ++s) rows_real += p.seg_m_host[s]; }
+    if (p.seg_m && !p.seg_m_host) return 1;
     // The results are bit-identical to lingemm's (same K order, same MFMA and operand roles, same epilogue), so the choice is
     // purely one of speed and may depend on the batch: 256-row tiles with one workgroup per CU pay when the tiles fill whole
     // rounds of the chip's CUs and few of their rows are padding.  (B = 32 x 4 s, HuBERT-base: the first four strided
     // convolutions and the QKV projection; FFN1's 300 tiles are 1.17 rounds and stay on the 128-row kernel.)
     const int opt = si_opt_gemm256(ctx);
     if (opt == 0) return 1;
+    if (si_num_cus(ctx) < 8) return 1;                                 // the XCD run split needs a grid that is a positive multiple of 8 (partitioned devices: lingemm)
     if (opt == 1) {
         const int cus = si_num_cus(ctx);
-        const long tiles = (long)p.nseg * mtiles * (p.N / G_BN);
+        const long tiles = row_blocks * (p.N / G_BN);
         const double fill = (double)tiles / (double)((tiles + cus - 1) / cus * cus);
-        const double rows = (double)p.M / ((double)mtiles * G_BM);
+        const double rows = rows_real / ((double)row_blocks * G_BM);
         if (fill * rows < 0.72) return 1;
     }
     const size_t lds = 5 * (size_t)G_PAIR;                             // all 160 KB of a CU's LDS
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(gemm256_kernel), lds)) return rc;
     LinGemmParams q = p;
-    const int tiles = p.nseg * mtiles * (p.N / G_BN);
+    const int tiles = (int)(row_blocks * (p.N / G_BN));
     q.xcd_rows = tiles;
     // One workgroup per CU; with more tiles than CUs a workgroup walks its XCD's run and requests the next tile's first K-tiles
     // under the last two of the current one.  Tiles must then start on ring slots 0 / 0: K a multiple of 6 K-tiles; otherwise
@@ -334,9 +344,9 @@ int si_launch_gemm256(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     const int cus = si_num_cus(ctx);
     q.persistent = (nk % 6 == 0 && run_max * 8 > cus) ? 1 : 0;
     const unsigned grid = (unsigned)(q.persistent ? std::min(run_max, cus / 8) * 8 : run_max * 8);
-    const double macs = (double)p.nseg * p.M * p.N * (double)p.K;
-    const double outs = (double)p.nseg * p.M * p.N;
-    const double bytes = 2.0 * p.nseg * ((double)p.M * p.lda + (p.K - p.lda > 0 ? p.K - p.lda : 0)) + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0)) + 2.0 * p.N * p.K;
+    const double macs = rows_real * p.N * (double)p.K;
+    const double outs = rows_real * p.N;
+    const double bytes = 2.0 * (rows_real * p.lda + p.nseg * (double)(p.K - p.lda > 0 ? p.K - p.lda : 0)) + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0)) + 2.0 * p.N * p.K;
     si_prof_begin(ctx, si_prof_shape_name("gemm256_bf16", p.M * (long)p.nseg, p.N, p.K), 2.0 * macs, bytes, st);
     hipLaunchKernelGGL(gemm256_kernel, dim3(grid), dim3(G_NT), lds, st, q);
     si_prof_end(ctx, st);

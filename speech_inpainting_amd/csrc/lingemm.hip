@@ -65,7 +65,7 @@ __device__ __forceinline__ int lg_swz(int row) { return ((row >> 1) & 3) << 5; }
 // accumulators -> fp32 image of the tile in LDS -> bias / GELU / residual -> row-contiguous stores
 template <int BM>
 __device__ __forceinline__ void lg_epilogue(const LinGemmParams& p, char* smem, const f32x4 (&acc)[BM / 32][4], int tid, int wm0, int wn0, int r16, int kg,
-                                            int seg, int m0, int n0) {
+                                            int seg, int m0, int n0, int Ms) {
 #pragma unroll
     for (int i = 0; i < BM / 32; ++i) {
         const int m = wm0 + 16 * i + r16;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void lg_epilogue(const LinGemmParams& p, char* smem, 
     for (int it = 0; it < BM / 8; ++it) {
         const int r = er0 + 8 * it;
         const int m = m0 + r;
-        if (m >= p.M) break;                                           // rows ascend with `it`
+        if (m >= Ms) break;                                            // rows ascend with `it`
         const long o = obase + (long)m * p.ldo + n;
         f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * 512 + ((c4 ^ (r & 15)) << 4));
 #pragma unroll
@@ -130,6 +130,8 @@ __global__ __launch_bounds__(LG_NT, 2) void lingemm_kernel(const LinGemmParams p
     const int seg = mt / mtiles;
     const int m0 = (mt - seg * mtiles) * LG_BM;
     const int n0 = (tile - mt * ntn) * LG_BN;
+    const int Ms = p.seg_m ? p.seg_m[seg] : p.M;                       // ragged batches: this segment's own rows (scalar load)
+    if (m0 >= Ms) return;
 
     // A rows through a descriptor over the whole activation buffer (reads past its end return zero; rows >= M of the last
     // tile of a segment read the next segment's data or zero and only feed output rows that are never stored)
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(LG_NT, 2) void lingemm_kernel(const LinGemmParams p
         if (c + 1 < nchunks) step(S0{}, c + 1);
     }
 
-    lg_epilogue<BM>(p, smem, acc, tid, wm0, wn0, r16, kg, seg, m0, n0);
+    lg_epilogue<BM>(p, smem, acc, tid, wm0, wn0, r16, kg, seg, m0, n0, Ms);
 }
 
 template <int BM>
@@ -251,9 +253,11 @@ static int lingemm_launch(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     const int rows_total = p.nseg * mtiles;
     q.xcd_rows = xcd ? rows_total : 0;
     const unsigned grid = (unsigned)((xcd ? (rows_total + 7) / 8 * 8 : rows_total) * (p.N / LG_BN));
-    const double macs = (double)p.nseg * p.M * p.N * (double)p.K;
-    const double outs = (double)p.nseg * p.M * p.N;
-    const double bytes = 2.0 * p.nseg * ((double)p.M * p.lda + (p.K - p.lda > 0 ? p.K - p.lda : 0)) + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0)) + 2.0 * p.N * p.K;
+    double rows_real = (double)p.nseg * p.M;                           // ragged batches: the rows that exist
+    if (p.seg_m_host) { rows_real = 0; for (int s = 0; s < p.nseg; ++s) rows_real += p.seg_m_host[s]; }
+    const double macs = rows_real * p.N * (double)p.K;
+    const double outs = rows_real * p.N;
+    const double bytes = 2.0 * (rows_real * p.lda + p.nseg * (double)(p.K - p.lda > 0 ? p.K - p.lda : 0)) + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0)) + 2.0 * p.N * p.K;
     char name[48];
     snprintf(name, sizeof(name), "lingemm_bf16_%dx128", BM);           // one family per instantiation, as rocprofv3 lists them
     si_prof_begin(ctx, si_prof_shape_name(name, p.M * (long)p.nseg, p.N, p.K), 2.0 * macs, bytes, st);
@@ -279,7 +283,7 @@ int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
         const long slots = 2L * si_num_cus(ctx);
         double best = 1e30;
         for (int cand : {128, 96, 64}) {
-            const long tiles = (long)p.nseg * ((p.M + cand - 1) / cand) * (p.N / LG_BN);
+            const long tiles = (p.seg_m_host ? si_vl_tiles(p.seg_m_host, p.nseg, cand) : (long)p.nseg * ((p.M + cand - 1) / cand)) * (p.N / LG_BN);
             const double cost = (double)((tiles + slots - 1) / slots) * (cand + 24);
             if (cost < best * 0.97) { best = cost; bm = cand; }        // ties and near-ties go to the taller tile
         }

@@ -89,7 +89,8 @@ __device__ __forceinline__ int rc_swz(int row) { return ((row >> 1) & 3) << 4; }
 
 }  // namespace
 
-template <bool ACC>
+// VL: ragged batches (respair_wide.hip)
+template <bool ACC, bool VL>
 __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Xs = smem;
@@ -108,7 +109,11 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
     const int H = c * (p.dil[0] + p.dil[1] + p.dil[2] + 3);            // rows lost per side over the three pairs: 6 (k - 1) for dilations (1, 3, 5)
     const int Rout = RC_R - 2 * H;
     const int tiles_x = (p.L + Rout - 1) / Rout;
-    const int total = tiles_x * p.B;
+    const int total = VL ? p.total_tiles : tiles_x * p.B;
+    auto tile_of = [&](int t, int& tb, int& tm0, int& tL) {            // tile -> clip, first output row, the clip's rows
+        if constexpr (VL) { const SiVlTile v = si_vl_tile(p.lens, p.B, Rout, t); tb = v.b; tm0 = v.row0; tL = v.L; }
+        else { tb = t / tiles_x; tm0 = (t - tb * tiles_x) * Rout; tL = p.L; }
+    };
     const int wbytes = k * RC_C * RC_ROWB;
 
     // ---- weights of one convolution -> registers -> LDS (all taps; [tap][n][ci] is one contiguous run)
@@ -131,9 +136,10 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
     // ---- the tile's rows of the input stream -> registers (rows outside the clip read as zero through the descriptor)
     u32x4 ry[RC_YSLOTS];
     auto issueY = [&](int t) {
-        const int tb = t / tiles_x;
-        const int g0 = (t - tb * tiles_x) * Rout - H;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + (long)tb * p.L * RC_C), 0, p.L * RC_C * 2, 0x00020000);
+        int tb, tm0, tL;
+        tile_of(t, tb, tm0, tL);
+        const int g0 = tm0 - H;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + (long)tb * p.L * RC_C), 0, tL * RC_C * 2, 0x00020000);
 #pragma unroll
         for (int i = 0; i < RC_YSLOTS; ++i) {
             const int q = tid + i * RC_NT;
@@ -233,11 +239,12 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
     RC_TL_DECL
     for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
         const int nxt = tile + (int)gridDim.x < total ? tile + (int)gridDim.x : tile;   // clamped: the loads stay unconditional
-        const int b = tile / tiles_x;
-        const int g0 = (tile - b * tiles_x) * Rout - H;                // clip row of tile row 0
+        int b, tm0, Lb;                                                // clip, first output row, the clip's rows
+        tile_of(tile, b, tm0, Lb);
+        const int g0 = tm0 - H;                                        // clip row of tile row 0
         const long seg = (long)b * p.L * RC_C;
-        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out16 + seg, 0, p.L * RC_C * 2, 0x00020000);
-        const bool edge = g0 < 0 || g0 + RC_R > p.L;                   // some rows of the tile lie outside the clip (workgroup-uniform)
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out16 + seg, 0, Lb * RC_C * 2, 0x00020000);
+        const bool edge = g0 < 0 || g0 + RC_R > Lb;                    // some rows of the tile lie outside the clip (workgroup-uniform)
 
         // ---- the tile (requested one tile ago, or at kernel entry) -> X raw, A leaky-ReLU(0.1) on the packed halves
 #pragma unroll
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
                 float inside[2] = {1.f, 1.f};
                 if constexpr (MASK) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) { const int g = g0 + wm0 + 16 * (2 * ip + u) + r16; inside[u] = (g >= 0 && g < p.L) ? 1.f : 0.f; }
+                    for (int u = 0; u < 2; ++u) { const int g = g0 + wm0 + 16 * (2 * ip + u) + r16; inside[u] = (g >= 0 && g < Lb) ? 1.f : 0.f; }
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
                     _Float16 inside[2] = {(_Float16)1.f, (_Float16)1.f};
                     if constexpr (MASK) {
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) { const int g = g0 + wm0 + 16 * (2 * ip + u) + r16; inside[u] = (g >= 0 && g < p.L) ? (_Float16)1.f : (_Float16)0.f; }
+                        for (int u = 0; u < 2; ++u) { const int g = g0 + wm0 + 16 * (2 * ip + u) + r16; inside[u] = (g >= 0 && g < Lb) ? (_Float16)1.f : (_Float16)0.f; }
                     }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
                     for (int i = 0; i < RC_RT; ++i) {
                         const int m = wm0 + 16 * i + r16;
                         const int g = g0 + m;
-                        const bool keep = m >= H && m < RC_R - H && g < p.L;
+                        const bool keep = m >= H && m < RC_R - H && g < Lb;
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
                             prev[i][j] = __builtin_amdgcn_raw_buffer_load_b64(orsrc, keep ? (g * RC_C + 16 * j + 4 * kg) * 2 : (int)0x80000000, 0, 0);
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(RC_NT, 1) void reschain_kernel(const ResChainParams
         for (int q = tid; q < Rout * 4; q += RC_NT) {
             const int r = H + (q >> 2), ch = q & 3;
             const int g = g0 + r;
-            if (g < p.L) {
+            if (g < Lb) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(Xs + r * RC_ROWB + ((ch << 4) ^ rc_swz(r)));
                 __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, (g * RC_C + 8 * ch) * 2, 0, 0);
             }
@@ -425,14 +432,21 @@ int si_launch_reschain(si_ctx* ctx, int C, const ResChainParams& p, hipStream_t 
     }
     const int H = (p.k - 1) / 2 * (p.dil[0] + p.dil[1] + p.dil[2] + 3);
     if (2 * H > RC_R / 4) return 1;                                    // more than a quarter of the tile recomputed: not worth chaining
-    auto kern = p.accumulate ? reschain_kernel<true> : reschain_kernel<false>;
+    if ((p.lens == nullptr) != (p.lens_host == nullptr)) return si_fail(ctx, SI_EINVAL, "reschain: ragged batches need the lengths on the device and on the host");
+    const bool vl = p.lens != nullptr;
+    auto kern = vl ? (p.accumulate ? reschain_kernel<true, true> : reschain_kernel<false, true>) : (p.accumulate ? reschain_kernel<true, false> : reschain_kernel<false, false>);
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), RC_LDS)) return rc;
     const int Rout = RC_R - 2 * H;
-    const int total = ((p.L + Rout - 1) / Rout) * p.B;
+    const int total = vl ? (int)si_vl_tiles(p.lens_host, p.B, Rout) : ((p.L + Rout - 1) / Rout) * p.B;
+    if (total <= 0) return SI_OK;
+    ResChainParams pk = p;
+    pk.total_tiles = total;
     const int grid = std::min(total, si_num_cus(ctx));
-    const double elems = (double)p.B * p.L * C;
+    double rows = (double)p.B * p.L;
+    if (vl) { rows = 0; for (int b = 0; b < p.B; ++b) rows += p.lens_host[b]; }
+    const double elems = rows * C;
     si_prof_begin(ctx, p.accumulate ? "reschain_f16_c32_acc" : "reschain_f16_c32", 3 * 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 3 * 2.0 * 2.0 * p.k * C * C, st);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(RC_NT), RC_LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(RC_NT), RC_LDS, st, pk);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

@@ -43,7 +43,8 @@ __device__ __forceinline__ int rpn_swz(int row) {
 
 // ACC: the launch adds into the previous contents of out16.  Without it the registers of the accumulate rows are free and
 // the NEXT tile's activation rows are requested before the last slab (respair_wide.hip).
-template <int C, int R1, int WARPS_M, int TPS, bool ACC>
+// VL: ragged batches (respair_wide.hip)
+template <int C, int R1, int WARPS_M, int TPS, bool ACC, bool VL>
 __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairParams p) {
     static_assert(R1 == WARPS_M * 64 && (C == 32 || C == 64), "64-row wave tiles over all C channels");
     constexpr int NT = 64 * WARPS_M;
@@ -83,7 +84,11 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
     const int R0 = R1 + (k - 1) * d;
     // ---- persistent workgroups: tile = (clip, row block); a workgroup walks tiles blockIdx.x, + gridDim.x, ...
     const int tiles_x = (p.L + BMo - 1) / BMo;
-    const int total = tiles_x * p.B;
+    const int total = VL ? p.total_tiles : tiles_x * p.B;
+    auto tile_of = [&](int t, int& tb, int& tm0, int& tL) {            // tile -> clip, first output row, the clip's rows
+        if constexpr (VL) { const SiVlTile v = si_vl_tile(p.lens, p.B, BMo, t); tb = v.b; tm0 = v.row0; tL = v.L; }
+        else { tb = t / tiles_x; tm0 = (t - tb * tiles_x) * BMo; tL = p.L; }
+    };
     const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w1), 0, k * C * C * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w2), 0, k * C * C * 2, 0x00020000);
 
@@ -113,9 +118,10 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
     const int yc = tid % CPR, yr0 = tid / CPR;
     u32x4 ry[YSLOTS];
     auto issueY = [&](int t) {
-        const int tb = t / tiles_x;
-        const int trow0 = (t - tb * tiles_x) * BMo - p2 - p1;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + (long)tb * p.L * C), 0, p.L * C * 2, 0x00020000);
+        int tb, tm0, tL;
+        tile_of(t, tb, tm0, tL);
+        const int trow0 = tm0 - p2 - p1;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + (long)tb * p.L * C), 0, tL * C * 2, 0x00020000);
 #pragma unroll
         for (int i = 0; i < YSLOTS; ++i)
             ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((trow0 + yr0 + i * YRPP) * C + 8 * yc) * 2, 0, 0);
@@ -130,12 +136,12 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
 
   for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
     const int nxt = tile + (int)gridDim.x < total ? tile + (int)gridDim.x : tile;   // clamped: the loads below stay unconditional
-    const int b = tile / tiles_x;
-    const int m0 = (tile - b * tiles_x) * BMo;                         // first output row of this tile
+    int b, m0, Lb;                                                     // clip, first output row of this tile, the clip's rows
+    tile_of(tile, b, m0, Lb);
     const int t_row0 = m0 - p2;                                        // clip row of intermediate row 0
     const long seg = (long)b * p.L * C;
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + seg), 0, p.L * C * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out16 + seg, 0, p.L * C * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + seg), 0, Lb * C * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out16 + seg, 0, Lb * C * 2, 0x00020000);
 
     // ---- slab 0 and the activation tile (both requested one tile ago, or at kernel entry) -> LDS: raw fp16 -> leaky-ReLU(0.1)
     //      on the packed halves (rows outside the clip read as zero)
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int grow = t_row0 + wm0 + 16 * (2 * ip + u) + r16;
-                    inside[u] = (!EDGE || (grow >= 0 && grow < p.L)) ? 1.f : 0.f;   // as a factor: no branch per element
+                    inside[u] = (!EDGE || (grow >= 0 && grow < Lb)) ? 1.f : 0.f;   // as a factor: no branch per element
                 }
                 const int ms = wm0 + 16 * (2 * ip + (kg & 1)) + r16;           // the row this lane stores after the trade
 #pragma unroll
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
                 }
             }
             };
-            if (t_row0 >= 0 && t_row0 + R1 <= p.L) epi1(std::false_type{});
+            if (t_row0 >= 0 && t_row0 + R1 <= Lb) epi1(std::false_type{});
             else epi1(std::true_type{});
             init_acc(Bs + C);
         }
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(64 * WARPS_M, 2) void respair_kernel(const ResPairP
     for (int it = 0; it < OPASS; ++it) {
         const int o = or0 + it * ORPP;
         const int grow = m0 + o;
-        goff[it] = (o < BMo && grow < p.L) ? (grow * C + 8 * c8) * 2 : (int)0x80000000;
+        goff[it] = (o < BMo && grow < Lb) ? (grow * C + 8 * c8) * 2 : (int)0x80000000;
         res[it] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, goff[it], 0, 0);
         if constexpr (ACC) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, goff[it], 0, 0);
     }
@@ -332,16 +338,23 @@ template <int C, int R1, int WARPS_M, int TPS>
 static int respair_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t st) {
     const int BMo = R1 - (p.k - 1);
     const size_t lds = (size_t)(R1 + RPN_HALO) * (C * 2 + (C == 64 ? 32 : 0)) + 2 * (size_t)TPS * C * C * 2 + 2 * (size_t)C * 4;
-    auto kern = p.accumulate ? respair_kernel<C, R1, WARPS_M, TPS, true> : respair_kernel<C, R1, WARPS_M, TPS, false>;
+    const bool vl = p.lens != nullptr;
+    auto kern = vl ? (p.accumulate ? respair_kernel<C, R1, WARPS_M, TPS, true, true> : respair_kernel<C, R1, WARPS_M, TPS, false, true>)
+                   : (p.accumulate ? respair_kernel<C, R1, WARPS_M, TPS, true, false> : respair_kernel<C, R1, WARPS_M, TPS, false, false>);
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), lds)) return rc;
     // persistent workgroups: as many as are resident at once (two per CU for the 4-wave C = 32 form), each walking tiles
-    const int total = ((p.L + BMo - 1) / BMo) * p.B;
+    const int total = vl ? (int)si_vl_tiles(p.lens_host, p.B, BMo) : ((p.L + BMo - 1) / BMo) * p.B;
+    if (total <= 0) return SI_OK;
+    ResPairParams pk = p;
+    pk.total_tiles = total;
     const int grid = std::min(total, si_num_cus(ctx) * (WARPS_M == 4 ? 2 : 1));
     char name[48];
     snprintf(name, sizeof(name), p.accumulate ? "respair_f16_c%d_acc" : "respair_f16_c%d", C);   // one family per instantiation
-    const double elems = (double)p.B * p.L * C;
+    double rows = (double)p.B * p.L;
+    if (vl) { rows = 0; for (int b = 0; b < p.B; ++b) rows += p.lens_host[b]; }
+    const double elems = rows * C;
     si_prof_begin(ctx, name, 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 2.0 * 2.0 * p.k * C * C, st);   // y read once (it is also the residual), out written [, previous out read]
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WARPS_M), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WARPS_M), lds, st, pk);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
@@ -349,11 +362,13 @@ static int respair_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t st) {
 
 // SI_OK when launched, negative on error, 1 when the shape is not covered (the caller launches the two convolutions).
 int si_launch_respair(si_ctx* ctx, int C, const unsigned short* y16, unsigned short* out16, const void* w1, const void* w2,
-                      const float* b1, const float* b2, int B, int L, int k, int dil, float alpha, int accumulate, hipStream_t st) {
+                      const float* b1, const float* b2, int B, int L, int k, int dil, float alpha, int accumulate, hipStream_t st,
+                      const int32_t* lens, const int32_t* lens_host) {
     if ((C != 32 && C != 64 && C != 128 && C != 256) || k < 3 || k > 11 || (k & 1) == 0 || (k - 1) * dil > 50 ||
         ((long)L + 1024) * C * 2 >= (1L << 31)) return 1;
     if (!b1 || !b2) return 1;
-    ResPairParams p{y16, out16, static_cast<const unsigned short*>(w1), static_cast<const unsigned short*>(w2), b1, b2, B, L, k, dil, alpha, accumulate};
+    if ((lens == nullptr) != (lens_host == nullptr)) return si_fail(ctx, SI_EINVAL, "respair: ragged batches need the lengths on the device and on the host");
+    ResPairParams p{y16, out16, static_cast<const unsigned short*>(w1), static_cast<const unsigned short*>(w2), b1, b2, B, L, k, dil, alpha, accumulate, lens, lens_host, 0};
     if (C >= 128) return si_launch_respair_wide(ctx, C, p, st);
     // C = 32: every tap of a convolution in one slab (11 x 2 KB), 256 rows, two 4-wave workgroups per CU
     // C = 64: 4 taps per slab (32 KB), 512 rows, one 8-wave workgroup per CU

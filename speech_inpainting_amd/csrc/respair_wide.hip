@@ -80,7 +80,8 @@ constexpr int RPW_HALO = 50;                                          // (k - 1)
 
 // ACC: the launch adds into the previous contents of out16 (last pair of the 2nd / 3rd resblock).  Without it the
 // registers of the accumulate rows are free and the NEXT tile's activation rows are prefetched under the last slab.
-template <int C, int R1, int WARPS_M, int WARPS_N, int BKW, bool ACC>
+// VL: ragged batches -- clip b holds p.lens[b] rows (at stride p.L); tiles are numbered clip by clip without gaps (si_vl_tile).
+template <int C, int R1, int WARPS_M, int WARPS_N, int BKW, bool ACC, bool VL>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel(const ResPairParams p) {
     static_assert((WARPS_M * WARPS_N == 8 || WARPS_M * WARPS_N == 4) && R1 == WARPS_M * 64 && C == WARPS_N * 64, "64 x 64 wave tiles");
     static_assert(BKW == 128 || BKW == 64, "weight-slab depth");
@@ -116,7 +117,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
     const int R0 = R1 + (k - 1) * d;
     // ---- persistent workgroups: tile = (clip, row block); a workgroup walks tiles blockIdx.x, + gridDim.x, ...
     const int tiles_x = (p.L + BMo - 1) / BMo;
-    const int total = tiles_x * p.B;
+    const int total = VL ? p.total_tiles : tiles_x * p.B;
+    auto tile_of = [&](int t, int& tb, int& tm0, int& tL) {            // tile -> clip, first output row, the clip's rows
+        if constexpr (VL) { const SiVlTile v = si_vl_tile(p.lens, p.B, BMo, t); tb = v.b; tm0 = v.row0; tL = v.L; }
+        else { tb = t / tiles_x; tm0 = (t - tb * tiles_x) * BMo; tL = p.L; }
+    };
     const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w1), 0, k * C * C * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w2), 0, k * C * C * 2, 0x00020000);
 
@@ -150,9 +155,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
     const int yc = tid % CPRY, yr0 = tid / CPRY;
     u32x4 ry[YSLOTS];
     auto issueY = [&](int t) {
-        const int tb = t / tiles_x;
-        const int trow0 = (t - tb * tiles_x) * BMo - p2 - p1;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + (long)tb * p.L * C), 0, p.L * C * 2, 0x00020000);
+        int tb, tm0, tL;
+        tile_of(t, tb, tm0, tL);
+        const int trow0 = tm0 - p2 - p1;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + (long)tb * p.L * C), 0, tL * C * 2, 0x00020000);
 #pragma unroll
         for (int i = 0; i < YSLOTS; ++i)
             ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((trow0 + yr0 + i * YRPP) * C + 8 * yc) * 2, 0, 0);
@@ -171,12 +177,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
 
   for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
     const int nxt = tile + (int)gridDim.x < total ? tile + (int)gridDim.x : tile;   // clamped: the loads below stay unconditional
-    const int b = tile / tiles_x;
-    const int m0 = (tile - b * tiles_x) * BMo;                         // first output row of this tile
+    int b, m0, Lb;                                                     // clip, first output row of this tile, the clip's rows
+    tile_of(tile, b, m0, Lb);
     const int t_row0 = m0 - p2;                                        // clip row of intermediate row 0
     const long seg = (long)b * p.L * C;
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + seg), 0, p.L * C * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out16 + seg, 0, p.L * C * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.y16 + seg), 0, Lb * C * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out16 + seg, 0, Lb * C * 2, 0x00020000);
 
     // ---- slab 0 and the activation tile (both requested one tile ago, or at kernel entry) -> LDS: raw fp16 -> leaky-ReLU(0.1)
     //      on the packed halves
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int grow = t_row0 + wm0 + 16 * (2 * ip + u) + r16;
-                    inside[u] = (grow >= 0 && grow < p.L) ? 1.f : 0.f;         // as a factor: no branch per element
+                    inside[u] = (grow >= 0 && grow < Lb) ? 1.f : 0.f;         // as a factor: no branch per element
                 }
                 const int ms = wm0 + 16 * (2 * ip + (kg & 1)) + r16;           // the row this lane stores after the trade
 #pragma unroll
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
     for (int it = 0; it < OPASS; ++it) {
         const int o = or0 + it * ORPP;
         const int grow = m0 + o;
-        goff[it] = (o < BMo && grow < p.L) ? (grow * C + 8 * c8) * 2 : (int)0x80000000;
+        goff[it] = (o < BMo && grow < Lb) ? (grow * C + 8 * c8) * 2 : (int)0x80000000;
         res[it] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, goff[it], 0, 0);
         if constexpr (ACC) prev[it] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, goff[it], 0, 0);
     }
@@ -381,16 +387,23 @@ static int respair_wide_launch(si_ctx* ctx, const ResPairParams& p0, hipStream_t
     const ResPairParams& p = p0;
     const int BMo = R1 - (p.k - 1);
     const size_t lds = (size_t)(R1 + RPW_HALO) * C * 2 + 2 * (size_t)C * BKW * 2 + 2 * (size_t)C * 4;
-    auto kern = p.accumulate ? respair_wide_kernel<C, R1, WARPS_M, WARPS_N, BKW, true> : respair_wide_kernel<C, R1, WARPS_M, WARPS_N, BKW, false>;
+    const bool vl = p0.lens != nullptr;
+    auto kern = vl ? (p.accumulate ? respair_wide_kernel<C, R1, WARPS_M, WARPS_N, BKW, true, true> : respair_wide_kernel<C, R1, WARPS_M, WARPS_N, BKW, false, true>)
+                   : (p.accumulate ? respair_wide_kernel<C, R1, WARPS_M, WARPS_N, BKW, true, false> : respair_wide_kernel<C, R1, WARPS_M, WARPS_N, BKW, false, false>);
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), lds)) return rc;
     // one persistent workgroup per CU (144-157 KB of LDS each) walking tiles blockIdx.x + i * gridDim.x
-    const int total = ((p.L + BMo - 1) / BMo) * p.B;
+    const int total = vl ? (int)si_vl_tiles(p.lens_host, p.B, BMo) : ((p.L + BMo - 1) / BMo) * p.B;
+    if (total <= 0) return SI_OK;
+    ResPairParams pk = p0;
+    pk.total_tiles = total;
     const int grid = std::min(total, si_num_cus(ctx) * (WARPS_M * WARPS_N == 4 ? 2 : 1));
     char name[48];
     snprintf(name, sizeof(name), p.accumulate ? "respair_f16_c%d_acc" : "respair_f16_c%d", C);   // one family per instantiation
-    const double elems = (double)p.B * p.L * C;
+    double rows = (double)p.B * p.L;
+    if (vl) { rows = 0; for (int b = 0; b < p.B; ++b) rows += p.lens_host[b]; }
+    const double elems = rows * C;
     si_prof_begin(ctx, name, 2.0 * 2.0 * elems * C * p.k, elems * (2.0 + 2.0 + (p.accumulate ? 2.0 : 0.0)) + 2.0 * 2.0 * p.k * C * C, st);   // y read once (it is also the residual), out written [, previous out read]
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WARPS_M * WARPS_N), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WARPS_M * WARPS_N), lds, st, pk);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

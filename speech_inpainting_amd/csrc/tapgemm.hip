@@ -120,6 +120,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
     const int m0 = (mt % mtiles) * BM;
     const int n0 = (tile % ntn) * BN;
     const int g = blockIdx.y;
+    // ragged batches: this segment's own row counts (wave-uniform scalar loads); a tile past its rows has nothing to do
+    const int Lin_s = p.seg_lin ? p.seg_lin[seg] : p.Lin;
+    if (p.seg_m && m0 >= p.seg_m[seg]) return;
+    const long olimit_s = p.seg_orows ? (long)p.seg_orows[seg] * p.olim_mul : p.olimit;
+    const long xseg0 = p.seg_row_off ? (long)p.seg_row_off[seg] * p.ldx : (long)seg * p.x_seg_stride;
+    const long oseg0 = p.seg_row_off ? (long)p.seg_row_off[seg] * p.ldo : (long)seg * p.o_seg_stride;
 
     const int adil = p.dil < 0 ? -p.dil : p.dil;
     const int dil_lo = p.dil < 0 ? (p.ntaps - 1) * p.dil : 0;
@@ -134,8 +140,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
     elem_t* As = reinterpret_cast<elem_t*>(smem);                 // [abufs][PLANES][rowsA][LD]
     elem_t* Bs = As + (size_t)abufs * a_tile;                     // [2][PLANES][BN][LD]
 
-    const float* xs = A16 ? nullptr : p.x + (long)seg * p.x_seg_stride + (long)g * p.Cin;
-    const unsigned short* xs16 = A16 ? p.x16 + (long)seg * p.x_seg_stride + (long)g * p.Cin : nullptr;
+    const float* xs = A16 ? nullptr : p.x + xseg0 + (long)g * p.Cin;
+    const unsigned short* xs16 = A16 ? p.x16 + xseg0 + (long)g * p.Cin : nullptr;
     const size_t wplane = (size_t)ntaps * p.Npad * p.Cin;        // elements per group
     const float slope = p.pro_slope;
 
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
     constexpr int AESZ = A16 ? 2 : 4;
     const void* const xbase = A16 ? static_cast<const void*>(xs16) : static_cast<const void*>(xs);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(xbase), 0, (int)(((long)p.Lin * p.ldx - (long)g * p.Cin) * AESZ), 0x00020000);
+        const_cast<void*>(xbase), 0, (int)(((long)Lin_s * p.ldx - (long)g * p.Cin) * AESZ), 0x00020000);
     static_assert(NT % V4 == 0, "slot i of a thread is row r0 + i * (NT / V4), same column group");
     const int a_r0 = tid / V4, a_j = tid - a_r0 * V4;
     const int a_voff = ((base_in + a_r0) * p.ldx + 4 * a_j) * AESZ;
@@ -448,8 +454,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
     // phase layout and (voffset forced to 2^31) the columns >= N, so no per-element predicate or address register
     // survives -- a lane keeps one byte offset per 32x32 tile and adds a scalar row step.
     // p.out may be NULL when only the operand-ready 16-bit copy is wanted (p.out16); the descriptor then has 0 records
-    float* const outp = p.out ? p.out + (long)seg * p.o_seg_stride : nullptr;
-    const float* const resp = p.res ? p.res + (long)seg * p.o_seg_stride : outp;
+    float* const outp = p.out ? p.out + oseg0 : nullptr;
+    const float* const resp = p.res ? p.res + oseg0 : outp;
     const bool has_res = p.res != nullptr || p.res16 != nullptr;
     const bool res_is16 = p.res16 != nullptr;
     const bool acc_out = p.accumulate != 0;
@@ -458,13 +464,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WavesPerSimd<BM, BN, 64 * 
     const bool has_o16 = p.out16 != nullptr;
     const float slope16 = p.out16_slope;
     const bool gelu = p.act == SI_ACT_GELU;
-    const int nbytes = (int)p.olimit * 4;
+    const int nbytes = (int)olimit_s * 4;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, has_out ? nbytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(resp), 0, resp ? nbytes : 0, 0x00020000);
-    unsigned short* const o16p = has_o16 ? p.out16 + (long)seg * p.o_seg_stride : nullptr;
+    unsigned short* const o16p = has_o16 ? p.out16 + oseg0 : nullptr;
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(o16p, 0, has_o16 ? nbytes / 2 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t r16rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short*>(res_is16 ? p.res16 + (long)seg * p.o_seg_stride : nullptr), 0, res_is16 ? nbytes / 2 : 0, 0x00020000);
+        const_cast<unsigned short*>(res_is16 ? p.res16 + oseg0 : nullptr), 0, res_is16 ? nbytes / 2 : 0, 0x00020000);
     auto from16 = [](unsigned short h) -> float {
         if constexpr (MATH == SI_MATH_F16) return (float)__builtin_bit_cast(_Float16, h);
         else return __builtin_bit_cast(float, (unsigned)h << 16);
@@ -754,7 +760,7 @@ int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t
     // the encoder's bf16 GEMMs and strided convolutions on operand-ready activations: the dedicated kernel (lingemm.hip)
     if (p.lingemm && math == SI_MATH_BF16 && p.x16 && p.groups == 1 && p.pad == 0 && p.dil == 1 && p.pro_slope == 1.f && p.alpha == 1.f &&
         !p.accumulate && !p.res16 && !p.acc16 && p.out16_slope == 1.f && p.ooff == 0 && (p.ntaps == 1 || p.ldx == p.Cin) && p.Npad == p.N &&
-        p.olimit == (long)p.M * p.ldo) {
+        p.olimit == (long)p.M * p.ldo && !p.seg_row_off && (!p.seg_m || (p.seg_orows == p.seg_m && p.olim_mul == p.ldo && p.seg_m_host))) {
         LinGemmParams q{};
         q.x16 = p.x16;
         const long xelems = p.nseg > 1 ? (long)p.nseg * p.x_seg_stride : (long)p.Lin * p.ldx;
@@ -765,6 +771,7 @@ int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t
         q.N = p.N; q.Cin = p.Cin; q.ntaps = p.ntaps; q.w_tap_stride = (long)p.Npad * p.Cin;
         q.bias = p.bias; q.res = p.res; q.out = p.out; q.out16 = p.out16; q.ldo = p.ldo; q.o_seg_stride = p.nseg > 1 ? p.o_seg_stride : 0;
         q.act = p.act;
+        q.seg_m = p.seg_m; q.seg_m_host = p.seg_m_host;                 // (ragged: rows >= seg_m[s] of a segment are neither computed nor stored)
         const int rc = si_launch_lingemm(ctx, q, st);
         if (rc <= 0) return rc;
     }

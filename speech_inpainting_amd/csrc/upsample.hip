@@ -34,7 +34,8 @@ constexpr int UP_TAPS = 2;
 }  // namespace
 
 // CIN input channels, N = stride * Cout GEMM columns (N == CIN for stride 2).  Waves: 4 along M x N / 64 along N, 64 x 64 tiles.
-template <int CIN, int N>
+// VL: ragged batches -- clip b holds p.lens_lin[b] input rows, p.lens_m[b] GEMM rows, p.lens_lin[b] * N output elements (common.h)
+template <int CIN, int N, bool VL>
 __global__ __launch_bounds__(64 * 4 * (N / 64), 2) void upsample_stream_kernel(const UpsampleParams p) {
     constexpr int WN = N / 64, NT = 64 * 4 * WN;
     constexpr int ROWB = CIN * 2 + 32;                                 // padded LDS row (activations and weights)
@@ -51,7 +52,12 @@ __global__ __launch_bounds__(64 * 4 * (N / 64), 2) void upsample_stream_kernel(c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
     const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 64;
-    const int tiles_x = (p.M + UP_RT - 1) / UP_RT, total = tiles_x * p.B;
+    const int tiles_x = (p.M + UP_RT - 1) / UP_RT, total = VL ? p.total_tiles : tiles_x * p.B;
+    // tile -> clip, first GEMM row, the clip's GEMM rows / input rows
+    auto tile_of = [&](int t, int& tb, int& tm0, int& tM, int& tLin) {
+        if constexpr (VL) { const SiVlTile v = si_vl_tile(p.lens_m, p.B, UP_RT, t); tb = v.b; tm0 = v.row0; tM = v.L; tLin = p.lens_lin[v.b]; }
+        else { tb = t / tiles_x; tm0 = (t - tb * tiles_x) * UP_RT; tM = p.M; tLin = p.Lin; }
+    };
 
     // ---- the input rows of a tile -> registers (rows before / after the clip read as zero through the clip's descriptor)
     // TWO tiles ahead (two register sets; one tile ahead measured the same: the layers run at 5.3 / 3.2 TB/s of mixed reads and writes)
@@ -59,8 +65,9 @@ __global__ __launch_bounds__(64 * 4 * (N / 64), 2) void upsample_stream_kernel(c
     auto issueA = [&](auto setc, int tile) {
         constexpr int SET = decltype(setc)::value;
         if (tile >= total) tile = total - 1;                           // clamped: the loads stay unconditional
-        const int tb = tile / tiles_x, m0 = (tile - tb * tiles_x) * UP_RT;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.x16 + (long)tb * p.Lin * CIN), 0, p.Lin * CIN * 2, 0x00020000);
+        int tb, m0, tM, tLin;
+        tile_of(tile, tb, m0, tM, tLin);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.x16 + (long)tb * p.Lin * CIN), 0, tLin * CIN * 2, 0x00020000);
 #pragma unroll
         for (int i = 0; i < ASLOTS; ++i) {
             const int q = tid + i * NT;
@@ -84,7 +91,9 @@ __global__ __launch_bounds__(64 * 4 * (N / 64), 2) void upsample_stream_kernel(c
 
     auto do_tile = [&](auto setc, int tile) {
         constexpr int SET = decltype(setc)::value;
-        const int b = tile / tiles_x, m0 = (tile - b * tiles_x) * UP_RT;
+        int b, m0, Mb, Linb;
+        tile_of(tile, b, m0, Mb, Linb);
+        const long oelems = VL ? (long)Linb * N : p.o_clip_elems;       // output elements of this clip
 #pragma unroll
         for (int i = 0; i < ASLOTS; ++i) {
             const int q = tid + i * NT;
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(64 * 4 * (N / 64), 2) void upsample_stream_kernel(c
         //      (one workgroup per CU: nothing overlaps the two extra barriers) stores straight from the accumulators, 64 contiguous
         //      bytes per 4 lanes: 84 us against 100 through the image.
         constexpr bool IMAGE = N == 64;
-        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out16 + (long)b * p.o_clip_stride, 0, (int)(p.o_clip_elems * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out16 + (long)b * p.o_clip_stride, 0, (int)(oelems * 2), 0x00020000);
         if constexpr (IMAGE) __syncthreads();                          // every wave has finished reading the input tile
 #pragma unroll
         for (int ip = 0; ip < 2; ++ip) {
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(64 * 4 * (N / 64), 2) void upsample_stream_kernel(c
                     *reinterpret_cast<u32x4*>(As + ms * ROWB + n * 2) = v;
                 } else {
                     const long e = (long)(m0 + ms) * N + n - p.ooff;
-                    const int off = (m0 + ms < p.M && e >= 0 && e < p.o_clip_elems) ? (int)(e * 2) : (int)0x80000000;
+                    const int off = (m0 + ms < Mb && e >= 0 && e < oelems) ? (int)(e * 2) : (int)0x80000000;
                     __builtin_amdgcn_raw_buffer_store_b128(v, ors, off, 0, 0);
                 }
             }
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(64 * 4 * (N / 64), 2) void upsample_stream_kernel(c
                 const int r = q / OCPR, c = q - r * OCPR;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(As + r * ROWB + c * 16);
                 const long e = (long)(m0 + r) * N + 8 * c - p.ooff;
-                const int off = (m0 + r < p.M && e >= 0 && e < p.o_clip_elems) ? (int)(e * 2) : (int)0x80000000;
+                const int off = (m0 + r < Mb && e >= 0 && e < oelems) ? (int)(e * 2) : (int)0x80000000;
                 __builtin_amdgcn_raw_buffer_store_b128(v, ors, off, 0, 0);
             }
         }
@@ -179,15 +188,21 @@ template <int CIN, int N>
 static int upsample_launch(si_ctx* ctx, const UpsampleParams& p, hipStream_t st) {
     constexpr int WN = N / 64;
     const size_t lds = (size_t)(UP_RT + UP_TAPS - 1 + UP_TAPS * N) * (CIN * 2 + 32);
-    auto kern = upsample_stream_kernel<CIN, N>;
+    const bool vl = p.lens_m != nullptr;
+    auto kern = vl ? upsample_stream_kernel<CIN, N, true> : upsample_stream_kernel<CIN, N, false>;
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), lds)) return rc;
-    const int total = ((p.M + UP_RT - 1) / UP_RT) * p.B;
+    const int total = vl ? (int)si_vl_tiles(p.lens_m_host, p.B, UP_RT) : ((p.M + UP_RT - 1) / UP_RT) * p.B;
+    if (total <= 0) return SI_OK;
+    UpsampleParams pk = p;
+    pk.total_tiles = total;
     const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
     const int grid = std::min(total, si_num_cus(ctx) * per_cu);
     char name[40];
     snprintf(name, sizeof(name), "upsample_f16_c%d", CIN);
-    si_prof_begin(ctx, name, 2.0 * p.B * p.Lin * (double)CIN * N * UP_TAPS, 2.0 * p.B * ((double)p.Lin * CIN + (double)p.o_clip_elems) + 2.0 * UP_TAPS * N * CIN, st);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * 4 * WN), lds, st, p);
+    double rows = (double)p.B * p.Lin;                                 // input rows that exist (lens_m = input rows + 1 for k 4 / stride 2)
+    if (vl) { rows = 0; for (int b = 0; b < p.B; ++b) rows += p.lens_m_host[b] > 0 ? p.lens_m_host[b] - 1 : 0; }
+    si_prof_begin(ctx, name, 2.0 * rows * (double)CIN * N * UP_TAPS, 2.0 * rows * ((double)CIN + N) + 2.0 * UP_TAPS * N * CIN, st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * 4 * WN), lds, st, pk);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
@@ -196,6 +211,7 @@ static int upsample_launch(si_ctx* ctx, const UpsampleParams& p, hipStream_t st)
 // SI_OK when launched, negative on error, 1 when the shape is not covered (the caller runs the tap-GEMM).
 int si_launch_upsample_stream(si_ctx* ctx, const UpsampleParams& p, hipStream_t st) {
     if (p.taps != UP_TAPS || p.N != p.Cin || !p.x16 || !p.out16 || !p.w || !p.bias || p.B <= 0 || p.M <= 0) return 1;
+    if (p.lens_m && (!p.lens_lin || !p.lens_m_host)) return si_fail(ctx, SI_EINVAL, "upsample: ragged batches need lens_lin, lens_m and lens_m_host");
     if (p.ooff % 8 || p.o_clip_elems % 8 || (long)p.Lin * p.Cin * 2 >= (1L << 31) || p.o_clip_elems * 2 >= (1L << 31) ||
         ((long)p.M + 256) * p.N * 2 >= (1L << 31)) return 1;
     if (p.Cin == 128) return upsample_launch<128, 128>(ctx, p, st);

@@ -11,15 +11,18 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void extend_mel_kernel(const float* __restrict__ mel, int D, int Tm, int Tout, int stretch,
-                                                         float rscale, float* __restrict__ out, int ldo) {
+__global__ __launch_bounds__(256) void extend_mel_kernel(const float* __restrict__ mel, int D, int Tms, int Touts, int stretch,
+                                                         float rscale, float* __restrict__ out, int ldo,
+                                                         const int32_t* __restrict__ tm_len, const int32_t* __restrict__ tout_len) {
     const int b = blockIdx.y;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    // ragged batches: the clip's own frame counts inside rows of stride Tms / Touts (the interpolation clamps at ITS last frame)
+    const int Tm = tm_len ? tm_len[b] : Tms, Tout = tout_len ? tout_len[b] : Touts;
     if (i >= (long)Tout * ldo) return;
     const int t = (int)(i / ldo), c = (int)(i - (long)t * ldo);
     float v = 0.f;
     if (c < D) {
-        const float* row = mel + ((long)b * D + c) * Tm;
+        const float* row = mel + ((long)b * D + c) * Tms;
         if (stretch) {
             // ATen area_pixel_compute_source_index: one fused multiply-add in fp32, clamped at 0
             float src = fmaf((float)t + 0.5f, rscale, -0.5f);
@@ -35,16 +38,16 @@ __global__ __launch_bounds__(256) void extend_mel_kernel(const float* __restrict
             v = row[t];
         }
     }
-    out[(long)b * Tout * ldo + i] = v;
+    out[(long)b * Touts * ldo + i] = v;
 }
 
 int si_launch_extend_mel(si_ctx* ctx, const float* mel, int B, int D, int Tm, int Tout, int stretch, float* out, int ldo,
-                         hipStream_t st) {
+                         hipStream_t st, const int32_t* tm_len, const int32_t* tout_len) {
     if (B <= 0 || Tout <= 0) return SI_OK;
     const float rscale = (float)(1.0 / (441.0 / 256.0));
     dim3 grid((unsigned)(((long)Tout * ldo + 255) / 256), B);
     si_prof_begin(ctx, "extend_mel", 3.0 * B * Tout * D, 4.0 * B * D * ((double)Tm + Tout), st);
-    hipLaunchKernelGGL(extend_mel_kernel, grid, dim3(256), 0, st, mel, D, Tm, Tout, stretch, rscale, out, ldo);
+    hipLaunchKernelGGL(extend_mel_kernel, grid, dim3(256), 0, st, mel, D, Tm, Tout, stretch, rscale, out, ldo, tm_len, tout_len);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
@@ -57,18 +60,20 @@ int si_launch_extend_mel(si_ctx* ctx, const float* mel, int B, int D, int Tm, in
 // stride it took 114 us per 32 clips, three times the HBM time of its input.
 // x16 (optional): the input as raw fp16 (the vocoder's fp16 activation stream) instead of fp32 x
 __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const unsigned short* __restrict__ x16,
-                                                        const float* __restrict__ w, const float* __restrict__ bias, int L, int C,
-                                                        int k, float* __restrict__ wav) {
+                                                        const float* __restrict__ w, const float* __restrict__ bias, int Ls, int C,
+                                                        int k, float* __restrict__ wav, const int32_t* __restrict__ lens) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ldx = C + 4;
     float* xs = reinterpret_cast<float*>(smem);              // [(256 + k - 1)][C + 4]
     float* ws = xs + (256 + k - 1) * ldx;                    // [k][C]
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * 256;
+    const int L = lens ? lens[b] : Ls;                        // ragged batches: the clip's own rows at stride Ls
+    if (t0 >= L) return;
     const int pad = k / 2;
     const int rows = 256 + k - 1;
     const int c4n = C / 4;
-    const long xoff = (long)b * L * C;
+    const long xoff = (long)b * Ls * C;
     for (int idx = threadIdx.x; idx < rows * c4n; idx += 256) {
         const int r = idx / c4n, j = idx - r * c4n;
         const int t = t0 - pad + r;
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
             for (int e = 0; e < 4; ++e) acc = fmaf(xv[e], wv[e], acc);
         }
     }
-    wav[(long)b * L + t] = tanhf(acc);
+    wav[(long)b * Ls + t] = tanhf(acc);
 }
 
 // The same tail on the fp16 activation stream (C = 32), on the matrix pipe: out[t] = sum_tap w[tap] . y[t + tap] is an N = 1 GEMM;
@@ -109,8 +114,10 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 #define CPM_ROWS 512
+template <bool VL>
 __global__ __launch_bounds__(256) void conv_post_mfma_kernel(const unsigned short* __restrict__ x16, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, int B, int L, float* __restrict__ wav) {
+                                                             const float* __restrict__ bias, int B, int L, float* __restrict__ wav,
+                                                             const int32_t* __restrict__ lens, int total_tiles) {
     constexpr int C = 32, K = 7, PAD = 3, NR = CPM_ROWS + K - 1;
     __shared__ __attribute__((aligned(16))) char ys[(NR + 2) * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -124,12 +131,17 @@ __global__ __launch_bounds__(256) void conv_post_mfma_kernel(const unsigned shor
     const float b0 = bias[0];
     // persistent workgroups: tile = (clip, 512-sample block); the rows of the NEXT tile are requested before this one is
     // computed (all of them in flight at once: one HBM round trip per tile, hidden behind the previous tile's work)
-    const int tiles_x = (L + CPM_ROWS - 1) / CPM_ROWS, total = tiles_x * B;
+    const int tiles_x = (L + CPM_ROWS - 1) / CPM_ROWS, total = VL ? total_tiles : tiles_x * B;
+    auto tile_of = [&](int t, int& tb, int& tt0, int& tL) {            // tile -> clip, first sample, the clip's samples (ragged: si_vl_tile)
+        if constexpr (VL) { const SiVlTile v = si_vl_tile(lens, B, CPM_ROWS, t); tb = v.b; tt0 = v.row0; tL = v.L; }
+        else { tb = t / tiles_x; tt0 = (t - tb * tiles_x) * CPM_ROWS; tL = L; }
+    };
     constexpr int NSLOT = (NR * 4 + 255) / 256;
     u32x4v raw[NSLOT];
     auto issue = [&](int tile) {
-        const int tb = tile / tiles_x, tt0 = (tile - tb * tiles_x) * CPM_ROWS;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x16 + (long)tb * L * C), 0, L * C * 2, 0x00020000);
+        int tb, tt0, tL;
+        tile_of(tile, tb, tt0, tL);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(x16 + (long)tb * L * C), 0, tL * C * 2, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
             const int q = tid + i * 256;
@@ -139,7 +151,8 @@ __global__ __launch_bounds__(256) void conv_post_mfma_kernel(const unsigned shor
     };
     issue(blockIdx.x);
     for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
-        const int b = tile / tiles_x, t0 = (tile - b * tiles_x) * CPM_ROWS;
+        int b, t0, Lb;
+        tile_of(tile, b, t0, Lb);
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) {
             const int q = tid + i * 256;
@@ -161,20 +174,25 @@ __global__ __launch_bounds__(256) void conv_post_mfma_kernel(const unsigned shor
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[k], y, acc, 0, 0, 0);
             }
             const int t = t0 + rt * 16 + r16;
-            if (kg == 0 && t < L) wav[(long)b * L + t] = tanhf(acc[0] + b0);
+            if (kg == 0 && t < Lb) wav[(long)b * L + t] = tanhf(acc[0] + b0);
         }
         __syncthreads();                                               // the tile is consumed: the next one may be staged
     }
 }
 
 int si_launch_conv_post(si_ctx* ctx, const float* x, const float* w, const float* bias, int B, int L, int C, int k, float* wav,
-                        hipStream_t st, const unsigned short* x16) {
+                        hipStream_t st, const unsigned short* x16, const int32_t* lens, const int32_t* lens_host) {
     if (C % 4 != 0) return si_fail(ctx, SI_EINVAL, "conv_post: C=%d must be a multiple of 4", C);
     if (B <= 0 || L <= 0) return SI_OK;
+    if ((lens == nullptr) != (lens_host == nullptr)) return si_fail(ctx, SI_EINVAL, "conv_post: ragged batches need the lengths on the device and on the host");
+    double rows = (double)B * L;
+    if (lens_host) { rows = 0; for (int b = 0; b < B; ++b) rows += lens_host[b]; }
     if (x16 && C == 32 && k == 7 && (long)L * C * 2 < (1L << 31)) {    // the fp16 stream's tail on the matrix pipe
-        si_prof_begin(ctx, "conv_post", 2.0 * B * L * (double)C * k, (double)B * L * (2.0 * C + 4.0), st);
-        const int total = ((L + CPM_ROWS - 1) / CPM_ROWS) * B;
-        hipLaunchKernelGGL(conv_post_mfma_kernel, dim3(std::min(total, si_num_cus(ctx) * 4)), dim3(256), 0, st, x16, w, bias, B, L, wav);
+        const int total = lens ? (int)si_vl_tiles(lens_host, B, CPM_ROWS) : ((L + CPM_ROWS - 1) / CPM_ROWS) * B;
+        if (total <= 0) return SI_OK;
+        si_prof_begin(ctx, "conv_post", 2.0 * rows * (double)C * k, rows * (2.0 * C + 4.0), st);
+        if (lens) hipLaunchKernelGGL(conv_post_mfma_kernel<true>, dim3(std::min(total, si_num_cus(ctx) * 4)), dim3(256), 0, st, x16, w, bias, B, L, wav, lens, total);
+        else hipLaunchKernelGGL(conv_post_mfma_kernel<false>, dim3(std::min(total, si_num_cus(ctx) * 4)), dim3(256), 0, st, x16, w, bias, B, L, wav, lens, total);
         si_prof_end(ctx, st);
         SI_HIP_CHECK(hipGetLastError());
         return SI_OK;
@@ -183,8 +201,8 @@ int si_launch_conv_post(si_ctx* ctx, const float* x, const float* w, const float
     if (lds > 160 * 1024) return si_fail(ctx, SI_EINVAL, "conv_post: %d channels x %d taps need %zu bytes of LDS (> 160 KiB)", C, k, lds);
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(conv_post_kernel), lds)) return rc;
     dim3 grid((L + 255) / 256, B);
-    si_prof_begin(ctx, "conv_post", 2.0 * B * L * (double)C * k, (double)B * L * ((x16 ? 2.0 : 4.0) * C + 4.0), st);
-    hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), lds, st, x, x16, w, bias, L, C, k, wav);
+    si_prof_begin(ctx, "conv_post", 2.0 * rows * (double)C * k, rows * ((x16 ? 2.0 : 4.0) * C + 4.0), st);
+    hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), lds, st, x, x16, w, bias, L, C, k, wav, lens);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

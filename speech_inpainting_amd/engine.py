@@ -62,29 +62,48 @@ class InpaintingEngine:
     # ---- weights
     def load_state(self, hubert_sd: Mapping[str, torch.Tensor], gen_sd: Mapping[str, torch.Tensor], codebook: Optional[torch.Tensor] = None):
         """hubert_sd: a CustomModel state dict, or the encoder alone (a HuggingFace directory / an I_da feature reader has no
-        `final_layers`: they are then initialised as the reference's constructor initialises them, I_ea/model.py:75-78).
-        codebook (K, codebook_dim) or None (I_da: the unit codebook lives in HuBERT feature space and is passed per call)."""
+        `final_layers`).  codebook (K, codebook_dim) or None (I_da: the unit codebook lives in HuBERT feature space and is passed
+        per call).  An engine without a trained head or without a codebook serves the encoder-only entry points
+        (`extract_features`, `ida_inpaint_batch`) and the vocoder; the I_ea calls that need the missing part (`encode`,
+        `predict_batch`, `splice`, `codebook_metrics`, ...) raise instead of computing on placeholders -- the reference's predict
+        path always loads the CustomModel .pt with its head (I_ea/predict.py:149) and its k-means model (:66-70)."""
         from .checkpoint import fresh_final_layers, normalize_hubert_keys
         hubert_sd = normalize_hubert_keys(hubert_sd)
-        if "final_layers.1.weight" not in hubert_sd:
-            hubert_sd.update(fresh_final_layers(self.harch))
+        self._has_head = "final_layers.1.weight" in hubert_sd
+        if not self._has_head:
+            hubert_sd.update(fresh_final_layers(self.harch))          # placeholder so that the packed layout is complete; never served
+        self._has_codebook = codebook is not None
         if codebook is None:
             codebook = torch.zeros(self.ctx.desc.num_clusters, self.harch.codebook_dim)
         blob, index = flatten_checkpoint(hubert_sd, gen_sd, codebook)
         self.ctx.load_weights(blob, index)
         return self
 
-    def alloc_weights(self):
+    def alloc_weights(self, has_head: bool = True, has_codebook: bool = True):
+        """Receiving rank of the weight broadcast: the flags say what the SOURCE rank's checkpoint held."""
         self.ctx.alloc_weights()
+        self._has_head, self._has_codebook = bool(has_head), bool(has_codebook)
         return self
+
+    def _need(self, head: bool = False, codebook: bool = False, what: str = "this call"):
+        if head and not getattr(self, "_has_head", True):
+            raise RuntimeError(f"{what} needs the trained `final_layers` head, but the loaded checkpoint held the encoder only "
+                               "(load the CustomModel .pt, I_ea/predict.py:149)")
+        if codebook and not getattr(self, "_has_codebook", True):
+            raise RuntimeError(f"{what} needs the k-means codebook, but none was loaded (load_state(..., codebook=...))")
 
     def weights_tensor(self) -> torch.Tensor:
         return self.ctx.weights_tensor()
+
+    def weights_check(self) -> None:
+        """After the weight broadcast: the blob in this context carries the fingerprint of THIS context's layout (raises otherwise)."""
+        self.ctx.weights_check()
 
     # ---- the three stages
     def encode(self, wave16: torch.Tensor, mask_start: Optional[torch.Tensor] = None, mask_len: Optional[torch.Tensor] = None,
                normalize: bool = True, valid_len: Optional[torch.Tensor] = None) -> torch.Tensor:
         """valid_len (B,) int32: real samples per clip of a RIGHT-PADDED batch (the reference's attention_mask.sum(-1))."""
+        self._need(head=True, what="encode")
         return self.ctx.hubert_forward(wave16, mask_start, mask_len, normalize, valid_len)
 
     def extract_features(self, wave16: torch.Tensor, output_layer: int, normalize="layer_norm",
@@ -138,10 +157,12 @@ class InpaintingEngine:
         return {"code": code, "code_inpainting": code_inp, "audio_gen": gen, "audio_inp": inp, "feats": hid}
 
     def splice(self, feats: torch.Tensor, frame_pos: torch.Tensor, lm: int, mel: torch.Tensor) -> torch.Tensor:
+        self._need(codebook=True, what="splice")
         return self.ctx.codebook_splice(feats, frame_pos, lm, mel)
 
     def splice_labels(self, labels: torch.Tensor, frame_pos: torch.Tensor, mel: torch.Tensor) -> None:
         """`expected_inpaint`'s splice (I_ea/predict.py:177-189): the raw centroids of GIVEN labels (B, Lm) into mel, in place."""
+        self._need(codebook=True, what="splice_labels")
         self.ctx.codebook_splice_labels(labels, frame_pos, mel)
 
     def vocode(self, mel: torch.Tensor, stretch: bool = True) -> torch.Tensor:
@@ -173,9 +194,56 @@ class InpaintingEngine:
     def codebook_metrics(self, feats: torch.Tensor, frame_pos: torch.Tensor, lm: int, target: torch.Tensor):
         """Loss half of the reference's cos_sim on the masked frames of `feats` (B, T, 80) against target labels
         (B, Lm): -> dict(loss, loss_terms, pred_labels, cos_pred_target, accuracy)."""
+        self._need(codebook=True, what="codebook_metrics")
         loss, terms, pred, cpt = self.ctx.codebook_metrics(feats, frame_pos, lm, target)
         return {"loss": loss[0], "loss_terms": terms, "pred_labels": pred, "cos_pred_target": cpt,
                 "accuracy": (pred == target).float().mean()}
+
+    # ---- ragged batches (BASELINE configs[4]): clips of different lengths in ONE set of launches
+    def encode_ragged(self, wave16: torch.Tensor, len16, mask_start: Optional[torch.Tensor] = None,
+                      mask_len: Optional[torch.Tensor] = None, normalize: bool = True) -> torch.Tensor:
+        """wave16 (B, Nmax): clip b = the first len16[b] samples of its row -> (B, Tmax, 80); each clip's frames equal that clip
+        encoded alone (the reference handles one file per run, I_ea/predict.py:76-207); rows past a clip's frames are zero."""
+        self._need(head=True, what="encode_ragged")
+        return self.ctx.hubert_forward_varlen(wave16, len16, mask_start, mask_len, normalize)
+
+    def mel_ragged(self, wave22: torch.Tensor, len22, mask_start: Optional[torch.Tensor] = None,
+                   mask_end: Optional[torch.Tensor] = None, normalize: bool = True) -> torch.Tensor:
+        """`mel` for clips of different lengths: (B, N22max) + per-clip sample counts -> (B, 80, Tm_max), zero frames past a clip's own."""
+        return self.ctx.mel_frontend_varlen(wave22, len22, mask_start, mask_end, normalize)
+
+    def vocode_ragged(self, mel: torch.Tensor, mel_len, stretch: bool = True) -> torch.Tensor:
+        return self.ctx.hifigan_forward_varlen(mel, mel_len, stretch)
+
+    def predict_ragged_batch(self, wave16: torch.Tensor, len16, mel: torch.Tensor, mel_len, frame_pos: torch.Tensor, frame_len: int,
+                             blind: bool = False, mask_start: Optional[torch.Tensor] = None,
+                             mask_len: Optional[torch.Tensor] = None) -> Dict[str, object]:
+        """`predict_batch` for clips of DIFFERENT lengths sharing every launch: wave16 (B, Nmax) / mel (B, 80, Tm_max) hold clip b in
+        the first len16[b] samples / mel_len[b] frames of its row (host int sequences).  Every clip's outputs equal that clip's
+        alone.  -> feats (B, Tmax, 80), labels (B, Lm) (-1 past a clip's own count in blind mode), mel, wave (B, Lmax; zero past a
+        clip's own samples), wave_len / frames / mel_len: per-clip valid extents (lists)."""
+        self._need(head=True, codebook=True, what="predict_ragged_batch")
+        B = wave16.shape[0]
+        len16 = [int(n) for n in len16]
+        mel_len = [int(n) for n in mel_len]
+        frames = [self.ctx.num_frames(n) for n in len16]
+        if blind:
+            feats = self.encode_ragged(wave16, len16)
+            pos = torch.zeros(B, dtype=torch.int32, device=self.device)
+            cnt_h = [min(t, m) for t, m in zip(frames, mel_len)]                   # predict_batch's `min(T, Tm)`, per clip
+        else:
+            if mask_start is None:
+                mask_start = frame_pos * 320 + 80                                   # predict.py:133
+                mask_len = torch.full_like(frame_pos, max(frame_len * 320 - 81, 0))
+            feats = self.encode_ragged(wave16, len16, mask_start.to(torch.int32), mask_len.to(torch.int32))
+            pos, cnt_h = frame_pos, [int(frame_len)] * B
+        lm = max(cnt_h)
+        cnt = torch.tensor(cnt_h, dtype=torch.int32, device=self.device)
+        mel2 = mel.clone()
+        labels = self.ctx.codebook_splice_varlen(feats, pos, cnt, lm, mel2)
+        wav = self.vocode_ragged(mel2, mel_len, stretch=True)
+        return {"feats": feats, "labels": labels, "mel": mel2, "wave": wav, "frames": frames, "mel_len": mel_len, "label_cnt": cnt_h,
+                "wave_len": [self.ctx.vocoder_samples(m, True) for m in mel_len]}
 
     def predict_batch(self, wave16: torch.Tensor, mel: torch.Tensor, frame_pos: torch.Tensor, frame_len: int,
                       blind: bool = False, mask_start: Optional[torch.Tensor] = None,
@@ -183,6 +251,7 @@ class InpaintingEngine:
         """wave16 (B, N) raw 16 kHz clips, mel (B, 80, Tm) log-mel of the masked 22.05 kHz clips, frame_pos (B,) int32
         first masked 20 ms frame, frame_len = Lm.  All tensors on this engine's GPU.  `mel` is not modified.
         blind=True replaces every frame (mask position unknown)."""
+        self._need(head=True, codebook=True, what="predict_batch")
         B = wave16.shape[0]
         if blind:
             feats = self.encode(wave16, None, None)
@@ -266,6 +335,7 @@ class LossFunction:
         """output (B, Lm, 80) gathered frames, labels (B, Lm) int64 -> (loss scalar tensor, pred_labels (B, Lm)),
         as I_ea/loss_fn.py:29-47 (called at I_ea/predict.py:171)."""
         dev = self.engine.device
+        self.engine._need(codebook=True, what="LossFunction.cos_sim")
         out = output.to(dev, torch.float32).contiguous()
         lab = labels.to(dev, torch.int64).contiguous()
         pos = torch.zeros(out.shape[0], dtype=torch.int32, device=dev)

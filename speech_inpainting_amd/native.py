@@ -21,7 +21,8 @@ SI_MATH = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, "fp16": 3, "f16": 3}
 SI_MAX_CONV, SI_MAX_UPS, SI_MAX_RB, SI_MAX_DIL = 8, 8, 4, 4
 
 EXPORTS = ["si_version", "si_create", "si_destroy", "si_last_error", "si_load_weights", "si_alloc_weights",
-           "si_weights_device_ptr", "si_workspace_bytes", "si_hubert_forward", "si_hubert_forward_padded", "si_hubert_extract_features", "si_code_splice", "si_codebook_splice",
+           "si_weights_device_ptr", "si_weights_check", "si_workspace_bytes", "si_hubert_forward", "si_hubert_forward_padded", "si_hubert_forward_varlen", "si_hubert_extract_features", "si_code_splice", "si_codebook_splice",
+           "si_codebook_splice_varlen", "si_hifigan_forward_varlen", "si_mel_frontend_varlen",
            "si_codebook_splice_labels", "si_codebook_metrics", "si_kmeans_assign", "si_mel_metrics", "si_sisdr", "si_unit_frontend",
            "si_f0_encoder_weight_floats", "si_f0_encoder_frames", "si_f0_encoder_workspace_bytes", "si_f0_encoder_forward",
            "si_resample_poly", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
@@ -152,9 +153,14 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.si_load_weights.argtypes = [vp, vp, sz, C.c_char_p]
     lib.si_alloc_weights.argtypes = [vp]
     lib.si_weights_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    lib.si_weights_check.argtypes = [vp]
     lib.si_workspace_bytes.argtypes = [vp, i32, i32, i32, C.POINTER(sz)]
     lib.si_hubert_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_hubert_forward_padded.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
+    lib.si_hubert_forward_varlen.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
+    lib.si_codebook_splice_varlen.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, i32, vp, vp]
+    lib.si_hifigan_forward_varlen.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
+    lib.si_mel_frontend_varlen.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_hubert_extract_features.argtypes = [vp, C.POINTER(ExtractDesc), vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
     lib.si_code_splice.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp]
     lib.si_codebook_splice.argtypes = [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp]
@@ -247,6 +253,10 @@ class NativeContext:
     def alloc_weights(self):
         self._check(self.lib.si_alloc_weights(self._h), "si_alloc_weights")
 
+    def weights_check(self):
+        """Compare the blob's layout fingerprint with this context's plan (after a broadcast); raises NativeError on a mismatch."""
+        self._check(self.lib.si_weights_check(self._h), "si_weights_check")
+
     def weights_ptr(self):
         """(device address, byte count) of the packed blob as si_weights_device_ptr reports it."""
         p, n = C.c_void_p(0), C.c_size_t(0)
@@ -303,6 +313,83 @@ class NativeContext:
         self._check(self.lib.si_hubert_forward_padded(self._h, _ptr(wav), _ptr(mask_start), _ptr(mask_len), _ptr(valid_len),
                                                       int(normalize), B, N, _ptr(out), _ptr(ws), ws.numel(), self._stream()),
                     "si_hubert_forward_padded")
+        return out
+
+    @staticmethod
+    def _host_lens(lens, B: int):
+        """HOST int32 (B) lengths of a ragged batch as a ctypes array (the library reads it during the call only)."""
+        a = np.ascontiguousarray(np.asarray(lens, dtype=np.int32).reshape(-1))
+        if a.size != B:
+            raise ValueError(f"ragged batch: {a.size} lengths for {B} clips")
+        return a
+
+    def hubert_forward_varlen(self, wav: torch.Tensor, sample_len, mask_start: Optional[torch.Tensor] = None,
+                              mask_len: Optional[torch.Tensor] = None, normalize: bool = True) -> torch.Tensor:
+        """RAGGED batch: wav (B, Nmax), clip b = the first sample_len[b] samples of its row (host ints) -> (B, Tmax, D) with zero
+        rows past each clip's own frames; every clip's rows equal that clip run alone (si_hubert_forward_varlen)."""
+        assert wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2 and wav.is_contiguous()
+        B, N = wav.shape
+        lens = self._host_lens(sample_len, B)
+        T = self.num_frames(N)
+        if T < 1:
+            raise ValueError(f"clip of {N} samples is too short")
+        for m in (mask_start, mask_len):
+            assert m is None or (m.is_cuda and m.dtype == torch.int32 and m.numel() == B and m.is_contiguous())
+        out = torch.empty(B, T, self.desc.codebook_dim, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, N, 0)
+        self._check(self.lib.si_hubert_forward_varlen(self._h, _ptr(wav), _ptr(mask_start), _ptr(mask_len), lens.ctypes.data_as(C.c_void_p),
+                                                      int(normalize), B, N, _ptr(out), _ptr(ws), ws.numel(), self._stream()),
+                    "si_hubert_forward_varlen")
+        return out
+
+    def codebook_splice_varlen(self, feats: torch.Tensor, frame_pos: torch.Tensor, frame_cnt: torch.Tensor, lm: int, mel: torch.Tensor) -> torch.Tensor:
+        """As codebook_splice with a per-clip frame count (B,) int32 on the device; labels past a clip's count are -1."""
+        assert feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous() and feats.dim() == 3
+        assert mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous() and mel.dim() == 3
+        B, T, D = feats.shape
+        for m in (frame_pos, frame_cnt):
+            assert m.is_cuda and m.dtype == torch.int32 and m.is_contiguous() and m.numel() == B
+        assert mel.shape[0] == B and mel.shape[1] == D
+        labels = torch.empty(B, lm, dtype=torch.int64, device=self.device)
+        self._check(self.lib.si_codebook_splice_varlen(self._h, _ptr(feats), B, T, _ptr(frame_pos), _ptr(frame_cnt), lm, _ptr(mel), mel.shape[2],
+                                                       _ptr(labels), self._stream()), "si_codebook_splice_varlen")
+        return labels
+
+    def hifigan_forward_varlen(self, mel: torch.Tensor, mel_len, stretch: bool = True) -> torch.Tensor:
+        """RAGGED batch: mel (B, D, Tm_max), clip b = its first mel_len[b] frames (host ints) -> (B, Lmax), the first
+        vocoder_samples(mel_len[b]) samples of row b equal that clip's waveform alone, the rest is zero."""
+        assert mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous() and mel.dim() == 3
+        B, D, Tm = mel.shape
+        assert D == self.desc.num_mels
+        lens = self._host_lens(mel_len, B)
+        L = self.vocoder_samples(Tm, stretch)
+        out = torch.empty(B, L, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, 0, Tm)
+        self._check(self.lib.si_hifigan_forward_varlen(self._h, _ptr(mel), lens.ctypes.data_as(C.c_void_p), B, Tm, int(stretch), _ptr(out),
+                                                       _ptr(ws), ws.numel(), self._stream()), "si_hifigan_forward_varlen")
+        return out
+
+    def mel_frontend_varlen(self, wave22: torch.Tensor, sample_len, mask_start: Optional[torch.Tensor] = None,
+                            mask_end: Optional[torch.Tensor] = None, normalize: bool = True) -> torch.Tensor:
+        """RAGGED batch: wave22 (B, N22max), clip b = its first sample_len[b] samples -> (B, 80, Tm_max), zero frames past a clip's own."""
+        assert wave22.is_cuda and wave22.dtype == torch.float32 and wave22.dim() == 2 and wave22.is_contiguous()
+        B, N = wave22.shape
+        lens = self._host_lens(sample_len, B)
+        Tm = int(self.lib.si_mel_frames(N))
+        if Tm < 1:
+            raise ValueError(f"clip of {N} samples is too short for the mel front-end")
+        assert (mask_start is None) == (mask_end is None)
+        for m in (mask_start, mask_end):
+            assert m is None or (m.is_cuda and m.dtype == torch.int32 and m.numel() == B and m.is_contiguous())
+        need = C.c_size_t(0)
+        self._check(self.lib.si_mel_workspace_bytes(self._h, B, N, C.byref(need)), "si_mel_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        out = torch.empty(B, 80, Tm, dtype=torch.float32, device=self.device)
+        self._check(self.lib.si_mel_frontend_varlen(self._h, _ptr(wave22), _ptr(mask_start), _ptr(mask_end), lens.ctypes.data_as(C.c_void_p),
+                                                    int(normalize), B, N, _ptr(out), _ptr(self._ws), self._ws.numel(), self._stream()),
+                    "si_mel_frontend_varlen")
         return out
 
     def hubert_extract_features(self, wav: torch.Tensor, output_layer: int, normalize="layer_norm",

@@ -47,6 +47,8 @@ def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
     staged through host memory around the same collective."""
     if not dist.is_initialized():
         return blob
+    if dist.get_backend() == "gloo" and dist.get_world_size() == 1:
+        return blob                         # nothing to stage (the world-size-1 collective is kept for RCCL only, where it is what the box can test)
     if blob.is_cuda and dist.get_backend() == "gloo":
         host = blob.cpu()
         dist.broadcast(host, src=src)
@@ -81,4 +83,5 @@ def setup_engine(make_engine, load_checkpoint, rank: int, src: int = 0):
     else:
         eng.alloc_weights()
     broadcast_blob(eng.weights_tensor(), src)
+    eng.weights_check()                # the received bytes were packed for THIS context's layout (desc + SI_VOC_* options)
     return eng

@@ -114,20 +114,99 @@ def bucket_by_length(lengths: Sequence[int], max_batch: int = 32) -> List[List[i
     return out
 
 
+def plan_ragged_batches(lengths: Sequence[int], max_batch: int = 32, max_waste: Optional[float] = None) -> List[List[int]]:
+    """Clip indices sorted by length (longest first) and cut into batches of at most `max_batch`; with `max_waste` a batch is also
+    closed before its STORAGE padding 1 - sum(len) / (n * longest) would exceed it.  (The kernels number their tiles clip by clip
+    without gaps, so padding costs memory, not launched work: one full batch fills the chip best.)"""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    out: List[List[int]] = []
+    cur: List[int] = []
+    tot = 0
+    for i in order:
+        n = int(lengths[i])
+        if cur:
+            longest = int(lengths[cur[0]])
+            waste = 1.0 - (tot + n) / ((len(cur) + 1) * longest)
+            if len(cur) >= max_batch or (max_waste is not None and waste > max_waste):
+                out.append(cur)
+                cur, tot = [], 0
+        cur.append(i)
+        tot += n
+    if cur:
+        out.append(cur)
+    return out
+
+
+def storage_padding(lengths: Sequence[int], batches: Sequence[Sequence[int]]) -> float:
+    """Fraction of the padded (batch, longest) storage that holds no sample, over all batches."""
+    real = sum(int(lengths[i]) for b in batches for i in b)
+    padded = sum(len(b) * max(int(lengths[i]) for i in b) for b in batches)
+    return 1.0 - real / max(padded, 1)
+
+
+def pad_stack(waves: Sequence[np.ndarray]) -> Tuple[torch.Tensor, List[int]]:
+    """Clips of different lengths -> pinned-memory-free (B, longest) float32 host tensor (zero tail) + their lengths."""
+    lens = [len(w) for w in waves]
+    out = torch.zeros(len(waves), max(lens), dtype=torch.float32)
+    for i, w in enumerate(waves):
+        out[i, :lens[i]] = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))
+    return out, lens
+
+
+def predict_clips_ragged(engine: InpaintingEngine, waves16: Sequence[np.ndarray], waves22: Sequence[np.ndarray],
+                         mask_pos: Sequence[int], mask_frames: int, blind: bool = False,
+                         mask22: Optional[Sequence[Tuple[int, int]]] = None) -> Dict[str, object]:
+    """`predict_clips` for clips of DIFFERENT lengths in ONE set of launches (the library's ragged-batch entry points): every
+    clip's outputs equal that clip's alone.  Tensors are (B, longest ...); `wave_len`, `frames`, `mel_len` give each clip's extent."""
+    dev = engine.device
+    if not blind:
+        for i, (a, b) in enumerate(zip(waves16, waves22)):
+            check_mask_span(engine, len(a), len(b), [mask_pos[i]], mask_frames)
+    w22, len22 = pad_stack(waves22)
+    w16, len16 = pad_stack(waves16)
+    wave22 = w22.to(dev)
+    if blind:
+        mel = engine.mel_ragged(wave22, len22)
+    else:
+        if mask22 is None:
+            mask22 = [(p * 320 * 22050 // 16000, (p + mask_frames) * 320 * 22050 // 16000) for p in mask_pos]
+        s22 = torch.tensor([min(max(int(a), 0), n) for (a, _), n in zip(mask22, len22)], dtype=torch.int32, device=dev)
+        e22 = torch.tensor([min(max(int(b), 0), n) for (_, b), n in zip(mask22, len22)], dtype=torch.int32, device=dev)
+        mel = engine.mel_ragged(wave22, len22, s22, e22)
+    mel_len = [engine.ctx.mel_frames(n) for n in len22]
+    pos = torch.tensor(list(mask_pos), dtype=torch.int32, device=dev)
+    out = engine.predict_ragged_batch(w16.to(dev), len16, mel, mel_len, pos, mask_frames, blind=blind)
+    out["mel_masked"] = mel
+    return out
+
+
 def predict_ragged(engine: InpaintingEngine, waves16: Sequence[np.ndarray], waves22: Sequence[np.ndarray],
-                   mask_pos: Sequence[int], mask_frames: int, blind: bool = False, max_batch: int = 32) -> List[Dict[str, torch.Tensor]]:
-    """`predict_clips` over clips of DIFFERENT lengths: exact-length buckets, one engine batch per bucket; returns one
-    result dict per input clip, in input order (tensors keep their batch dimension of 1)."""
+                   mask_pos: Sequence[int], mask_frames: int, blind: bool = False, max_batch: int = 32,
+                   max_waste: Optional[float] = None, exact_length: bool = False) -> List[Dict[str, torch.Tensor]]:
+    """The path over clips of DIFFERENT lengths (BASELINE configs[4]; the reference runs one file of any length per invocation,
+    I_ea/predict.py:76-207): clips are sorted by length and cut into ragged batches (`plan_ragged_batches`) that share every
+    launch; each clip's result equals that clip run alone.  Returns one dict per input clip, in input order, cut to the clip's own
+    extent (tensors keep a batch dimension of 1).  exact_length=True is the older route -- batches of EXACTLY equal length through
+    the uniform entry points (singletons on continuous lengths) -- kept as the reference the ragged route is tested against."""
     if not (len(waves16) == len(waves22) == len(mask_pos)):
         raise ValueError("waves16, waves22 and mask_pos must have one entry per clip")
     results: List[Optional[Dict[str, torch.Tensor]]] = [None] * len(waves16)
-    # a bucket must agree on BOTH sample counts (the 22.05 kHz length follows from the resampler's rounding)
-    keys = [len(a) * 1_000_003 + len(b) for a, b in zip(waves16, waves22)]
-    for idx in bucket_by_length(keys, max_batch):
-        out = predict_clips(engine, [waves16[i] for i in idx], [waves22[i] for i in idx], [mask_pos[i] for i in idx],
-                            mask_frames, blind=blind)
+    if exact_length:
+        # a bucket must agree on BOTH sample counts (the 22.05 kHz length follows from the resampler's rounding)
+        keys = [len(a) * 1_000_003 + len(b) for a, b in zip(waves16, waves22)]
+        for idx in bucket_by_length(keys, max_batch):
+            out = predict_clips(engine, [waves16[i] for i in idx], [waves22[i] for i in idx], [mask_pos[i] for i in idx],
+                                mask_frames, blind=blind)
+            for k, i in enumerate(idx):
+                results[i] = {name: v[k:k + 1] for name, v in out.items()}
+        return results  # type: ignore[return-value]
+    for idx in plan_ragged_batches([len(w) for w in waves16], max_batch, max_waste):
+        out = predict_clips_ragged(engine, [waves16[i] for i in idx], [waves22[i] for i in idx], [mask_pos[i] for i in idx],
+                                   mask_frames, blind=blind)
         for k, i in enumerate(idx):
-            results[i] = {name: v[k:k + 1] for name, v in out.items()}
+            T, Tm, nl, nw = out["frames"][k], out["mel_len"][k], out["label_cnt"][k], out["wave_len"][k]
+            results[i] = {"feats": out["feats"][k:k + 1, :T], "labels": out["labels"][k:k + 1, :nl], "mel": out["mel"][k:k + 1, :, :Tm],
+                          "mel_masked": out["mel_masked"][k:k + 1, :, :Tm], "wave": out["wave"][k:k + 1, :nw]}
     return results  # type: ignore[return-value]
 
 

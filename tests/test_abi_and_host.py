@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/si_hip.h but not exported"
     assert set(names) == set(native.EXPORTS), (set(names) ^ set(native.EXPORTS))
-    assert lib.si_version() == 2
+    assert lib.si_version() == 3
 
 
 def test_desc_struct_matches_header_size():

@@ -35,6 +35,9 @@ class _FakeEngine:
     def weights_tensor(self):
         return self.blob
 
+    def weights_check(self):
+        self.checked = True
+
 
 def _worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -50,6 +53,7 @@ def _worker(rank, world, port, q):
     eng = parallel.setup_engine(_FakeEngine, lambda: (loads.append(1), None, None), rank)
     assert len(loads) == (1 if rank == 0 else 0)              # only the source rank reads the checkpoint
     assert torch.equal(eng.weights_tensor(), torch.arange(1000, dtype=torch.uint8) * 3)
+    assert eng.checked                                            # the layout check runs on every rank after the broadcast
     # shard a global list of 5 utterances; each rank runs its slice; outputs must equal the 1-process run
     harch, varch = HubertArch.tiny(), VocoderArch.tiny()
     hsd, gsd, cb = synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook()

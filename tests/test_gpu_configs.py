@@ -328,9 +328,15 @@ def test_local_huggingface_directory_loads_and_encodes_like_the_pt_route(tmp_pat
     a = InpaintingEngine(arch_dir, varch, 100, "cuda:0", "bf16", "fp16").load_state(sd_dir, gsd, cb).encode(wave)
     b = InpaintingEngine(harch, varch, 100, "cuda:0", "bf16", "fp16").load_state(sd_pt, gsd, cb).encode(wave)
     assert torch.equal(a, b)
-    # the directory alone (no trained head): the engine initialises final_layers as the reference's constructor does
-    c = InpaintingEngine(arch_dir, varch, 100, "cuda:0").load_state(checkpoint.load_hubert_checkpoint(str(d))[0], gsd, cb).encode(wave)
-    assert c.shape == a.shape and bool(torch.isfinite(c).all())
+    # the directory alone (no trained head, no codebook): the encoder-only entry point serves, the I_ea calls that need the
+    # missing parts refuse instead of computing on placeholders
+    e = InpaintingEngine(arch_dir, varch, 100, "cuda:0").load_state(checkpoint.load_hubert_checkpoint(str(d))[0], gsd, None)
+    hid = e.extract_features(wave, harch.num_hidden_layers)
+    assert hid.shape == (2, harch.num_frames(8000), harch.hidden_size) and bool(torch.isfinite(hid).all())
+    with pytest.raises(RuntimeError, match="final_layers"):
+        e.encode(wave)
+    with pytest.raises(RuntimeError, match="codebook"):
+        e.splice(a, torch.zeros(2, dtype=torch.int32, device="cuda"), 2, torch.zeros(2, 80, 30, device="cuda"))
 
 
 @pytest.mark.gpu

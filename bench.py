@@ -200,6 +200,171 @@ def spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def timed_leg(eng, step, steps, warmup):
+    """`step()` timed over `steps` passes (no HIP events in the timed region), then 2 passes with every launch bracketed for
+    the per-family table and the dominant kernel's roofline object.  -> (seconds per step, roofline, families, last output)."""
+    for _ in range(warmup):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    eng.ctx.profile_filter(None)
+    eng.ctx.profile_start(8000)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    prof = eng.ctx.profile_stop()
+    roof, fams, tot = roofline_of(prof, 2)
+    roof["kernel_ms_per_step"] = round(tot / 2, 3)
+    return wall, roof, fams, out
+
+
+def leg_configs4(dev, enc, voc, steps):
+    """BASELINE configs[4]: blind inpainting on variable-length clips -- 32 clips per GPU, lengths U[4 s, 10 s] seed 1234 (SURVEY 8(d)
+    config #5), HuBERT-base + HiFi-GAN V1.  Three routes over the same resident clips: ONE ragged batch (every launch shared, tiles
+    numbered without gaps), ragged sub-batches cut at 15 % storage padding, and the exact-length route (one uniform launch set per
+    clip, what `predict_ragged` did before).  RTF = true audio-seconds / wall."""
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch, algorithmic_gmac, mel_frames
+    from speech_inpainting_amd.engine import InpaintingEngine
+    from speech_inpainting_amd.predict import plan_ragged_batches, storage_padding
+    harch, varch = HubertArch.base(), VocoderArch.v1()
+    B = 32
+    g = torch.Generator().manual_seed(1234)
+    secs = (4.0 + 6.0 * torch.rand(B, generator=g)).tolist()
+    n16 = [int(round(s * 16000)) for s in secs]
+    n22 = [-(-n * 441 // 320) for n in n16]
+    w16 = [synth.synth_wave(1, n, synth.DEFAULT_SEED + 40 + i)[0] for i, n in enumerate(n16)]
+    w22 = [synth.synth_wave(1, n, synth.DEFAULT_SEED + 90 + i, sr=22050)[0] for i, n in enumerate(n22)]
+    eng = InpaintingEngine(harch, varch, 100, dev, enc, voc).load_state(synth.synth_hubert_state(harch), synth.synth_generator_state(varch),
+                                                                       synth.synth_codebook(100))
+    audio_s = sum(n / 16000.0 for n in n16)
+    gflop = sum(2.0 * sum(algorithmic_gmac(harch, varch, a, mel_frames(b))) for a, b in zip(n16, n22))
+
+    def resident(idx):
+        a = torch.zeros(len(idx), max(n16[i] for i in idx))
+        b = torch.zeros(len(idx), max(n22[i] for i in idx))
+        for k, i in enumerate(idx):
+            a[k, :n16[i]] = w16[i]
+            b[k, :n22[i]] = w22[i]
+        return a.to(dev), [n16[i] for i in idx], b.to(dev), [n22[i] for i in idx], torch.zeros(len(idx), dtype=torch.int32, device=dev)
+
+    def route(plan):
+        groups = [resident(idx) for idx in plan]
+
+        def step():
+            out = None
+            for a, la, b, lb, pos in groups:
+                mel = eng.mel_ragged(b, lb)
+                out = eng.predict_ragged_batch(a, la, mel, [mel_frames(n) for n in lb], pos, 0, blind=True)
+            return out
+        return step
+
+    res = {"workload": "BASELINE configs[4]: blind inpainting, 32 clips per GPU, lengths U[4 s, 10 s] (seed 1234), HuBERT-base + HiFi-GAN V1; "
+                       "step = log-mel front-end -> encoder -> arg-max over ALL frames / splice -> vocoder on resident raw clips",
+           "clips": B, "audio_seconds": round(audio_s, 2), "gflop_algorithmic": round(gflop, 1), "dtype": f"encoder {enc}, vocoder {voc}"}
+    one = plan_ragged_batches(n16, B)
+    sub = plan_ragged_batches(n16, B, 0.15)
+    wall, roof, fams, out = timed_leg(eng, route(one), steps, 2)
+    finite = bool(torch.isfinite(out["wave"]).all())
+    res.update({"value": round(audio_s / wall, 2), "unit": "x real-time (true audio-sec/wall-sec)", "ms_per_step": round(1e3 * wall, 3), "steps": steps,
+                "route": "one ragged batch of 32 (every launch shared; tiles numbered clip by clip without gaps)",
+                "storage_padding": round(storage_padding(n16, one), 4), "launched_tile_padding": 0.0,
+                "achieved_tflops_whole_path": round(gflop / wall / 1e3, 2), "roofline": roof, "kernel_families": fams, "finite": finite})
+    wall_s, _, _, _ = timed_leg(eng, route(sub), steps, 1)
+    res["ragged_subbatches"] = {"value": round(audio_s / wall_s, 2), "ms_per_step": round(1e3 * wall_s, 3), "batches": [len(b) for b in sub],
+                                "storage_padding": round(storage_padding(n16, sub), 4),
+                                "route": "ragged batches cut where storage padding would exceed 15 %"}
+    # exact-length route: uniform entry points, one clip per launch set (continuous lengths: every bucket is a singleton)
+    singles = [(w16[i][None].to(dev), w22[i][None].to(dev)) for i in range(B)]
+    zero = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def exact_step():
+        out = None
+        for a, b in singles:
+            out = eng.predict_batch(a, eng.mel(b), zero, 0, blind=True)
+        return out
+    for _ in range(1):
+        exact_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_exact = max(1, steps // 2)
+    for _ in range(n_exact):
+        exact_step()
+    torch.cuda.synchronize()
+    wall_e = (time.perf_counter() - t0) / n_exact
+    res["exact_length_route"] = {"value": round(audio_s / wall_e, 2), "ms_per_step": round(1e3 * wall_e, 3), "launch_sets": B,
+                                 "route": "exact-length buckets through the uniform entry points: 32 singletons"}
+    del eng
+    return res
+
+
+def leg_configs3(dev, enc, voc, steps):
+    """BASELINE configs[3] per GPU (batch 128 over 8 GPUs = 16 clips): (a) the I_ea path with the HuBERT-LARGE encoder and a 400 ms
+    mask -- what the shipped I_ea/predict.yaml:27-28,39 selects -- and (b) I_da's inpainting() (I_da/scripts/inpainting.py:151-266):
+    HuBERT-large features at layer 18 of the clean and the corrupted clips, k-means units, unit splice, F0 VQ-VAE, unit HiFi-GAN,
+    both waveforms."""
+    from speech_inpainting_amd import native, synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch, algorithmic_gmac, mel_frames
+    from speech_inpainting_amd.engine import CodeGenerator, F0Quantizer, InpaintingEngine
+    harch = HubertArch.large()
+    B, N, K = 16, N_SAMPLES, 100
+    out = {}
+    hsd = synth.synth_hubert_state(harch, 77)
+    # ---- (a) I_ea, large encoder, Lm = 20
+    varch = VocoderArch.v1()
+    eng = InpaintingEngine(harch, varch, K, dev, enc, voc).load_state(hsd, synth.synth_generator_state(varch), synth.synth_codebook(K))
+    lm = 20
+    T, Tm = harch.num_frames(N), mel_frames(N * 22050 // 16000)
+    wave = synth.synth_wave(B, N, synth.DEFAULT_SEED + 3).to(dev)
+    wave22 = synth.synth_wave(B, N * 22050 // 16000, synth.DEFAULT_SEED + 6, sr=22050).to(dev)
+    pos = synth.synth_mask_frames(B, T, lm, synth.DEFAULT_SEED + 5).to(dev)
+    ms, ml = (pos * 320 + 80).to(torch.int32), torch.full_like(pos, lm * 320 - 81)
+    s22, e22 = (pos * 320 * 22050 // 16000).to(torch.int32), ((pos + lm) * 320 * 22050 // 16000).to(torch.int32)
+
+    def step_iea():
+        return eng.predict_batch(wave, eng.mel(wave22, s22, e22), pos, lm, mask_start=ms, mask_len=ml)
+    wall, roof, fams, o = timed_leg(eng, step_iea, steps, 2)
+    gflop = B * 2.0 * sum(algorithmic_gmac(harch, varch, N, Tm))
+    out["configs3_iea_large"] = {
+        "workload": "BASELINE configs[3] per GPU: 16 x 4 s clips, HuBERT-LARGE (24 pre-LN layers, LayerNorm feature extractor) + HiFi-GAN V1, 400 ms mask "
+                    "(I_ea/predict.yaml:27-28,39); step = log-mel front-end -> encoder -> arg-max/splice -> vocoder",
+        "value": round(B * CLIP_SECONDS / wall, 2), "unit": "x real-time (audio-sec/wall-sec)", "ms_per_step": round(1e3 * wall, 3), "steps": steps,
+        "clips": B, "dtype": f"encoder {enc}, vocoder {voc}", "gflop_algorithmic": round(gflop, 1),
+        "achieved_tflops_whole_path": round(gflop / wall / 1e3, 2), "roofline": roof, "kernel_families": fams,
+        "finite": bool(torch.isfinite(o["wave"]).all())}
+    del eng
+    # ---- (b) I_da inpainting(), layer 18, unit HiFi-GAN (hubert_lut.json shapes)
+    L = 18
+    uarch = VocoderArch(upsample_rates=(5, 4, 4, 2, 2), upsample_kernel_sizes=(11, 8, 8, 4, 4), upsample_initial_channel=512, num_mels=384,
+                        sampling_rate=16000)
+    enc_sd = {k: v for k, v in hsd.items() if k.startswith("base_model.")}
+    eng = InpaintingEngine(harch, uarch, K, dev, enc, voc).load_state(enc_sd, synth.synth_generator_state(uarch, 78))
+    g = torch.Generator().manual_seed(1)
+    gen = CodeGenerator(eng, torch.randn(K, 128, generator=g) * 0.5, torch.randn(20, 128, generator=g) * 0.5,
+                        f0_quantizer=F0Quantizer(eng, synth.synth_f0_vqvae_state(native.F0EncDesc(), 20, seed=79)))
+    wave = synth.synth_wave(B, N, 81).to(dev)
+    cent = torch.randn(K, harch.hidden_size, generator=g).to(dev)
+    f0 = torch.randn(B, 1, N // 80 - 3, generator=g).to(dev)
+    spk = (torch.randn(B, 128, generator=g) * 0.5).to(dev)
+
+    def step_ida():
+        return eng.ida_inpaint_batch(wave, 24000, 6400, cent, gen, f0, spk, output_layer=L)
+    wall, roof, fams, o = timed_leg(eng, step_ida, steps, 2)
+    out["configs3_ida"] = {
+        "workload": "BASELINE configs[3] per GPU, I_da's inpainting(): 16 x 4 s clips, 400 ms mask at 1.5 s, HuBERT-large features at layer 18 of the clean "
+                    "AND the corrupted clips (one 32-clip encoder pass), k-means units (K = 100), unit splice, F0 VQ-VAE, unit HiFi-GAN (ups 5,4,4,2,2): "
+                    "both waveforms (I_da/scripts/inpainting.py:151-266)",
+        "value": round(B * CLIP_SECONDS / wall, 2), "unit": "x real-time (audio-sec of the INPUT clips/wall-sec; two waveforms per clip are produced)",
+        "ms_per_step": round(1e3 * wall, 3), "steps": steps, "clips": B, "dtype": f"encoder {enc}, unit vocoder {voc}",
+        "roofline": roof, "kernel_families": fams, "finite": bool(torch.isfinite(o["audio_inp"]).all() and torch.isfinite(o["audio_gen"]).all())}
+    del eng
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,6 +378,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the secondary exact-fp32-vocoder leg")
     ap.add_argument("--graph-leg", action="store_true", help="also replay the step as one hipGraph (informational)")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the configs[3] / configs[4] legs (extra keys of the JSON line)")
+    ap.add_argument("--only-config-legs", action="store_true", help="diagnostic: run ONLY the configs[3] / configs[4] legs and print them")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -233,6 +400,13 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     dev = torch.device("cuda", local_rank if local_rank < torch.cuda.device_count() else 0)
     torch.cuda.set_device(dev)
+
+    if a.only_config_legs:
+        if rank == 0:
+            r = {"configs4": leg_configs4(dev, a.encoder_dtype, a.vocoder_dtype, max(3, a.steps // 2))}
+            r.update(leg_configs3(dev, a.encoder_dtype, a.vocoder_dtype, max(3, a.steps // 2)))
+            print(json.dumps(r), flush=True)
+        return
 
     harch, varch = HubertArch.base(), VocoderArch.v1()
     K = 100
@@ -328,9 +502,10 @@ def main():
         del eng
         elapsed_max = float(stats[:, 0].max())
         clips = float(stats[:, 1].sum())
+        clips_slowest = float(stats[int(stats[:, 0].argmax()), 1])           # the clips of the rank that set the wall time
         if not bool(stats[:, 3].min()):
             raise SystemExit("non-finite samples in the output waveform")
-        return dict(elapsed=elapsed_max, clips=clips, rms=float(stats[0, 2]), prof=prof, steps=steps, prof_warm=prof_warm, graph_ms=graph_ms,
+        return dict(elapsed=elapsed_max, clips=clips, clips_slowest_rank=clips_slowest, rms=float(stats[0, 2]), prof=prof, steps=steps, prof_warm=prof_warm, graph_ms=graph_ms,
                     warm_steps=warm_steps,
                     wave=wav if rank == 0 else None, labels=out["labels"] if rank == 0 else None)
 
@@ -353,8 +528,9 @@ def main():
                  "fp16": "fp16 MFMA (operands rounded to fp16, saturating), fp32 accumulate, activations stored as fp16"}
     clips = main_run["clips"]
     res = {
-        "metric": "real-time factor (audio-sec/wall-sec), 4 s clips @16 kHz, 200 ms mask",
-        "value": round(headline(main_run), 2), "unit": "x real-time (audio-sec/wall-sec), whole job",
+        "metric": "real-time factor (audio-sec/wall-sec) per GPU, 4 s clips @16 kHz, 200 ms mask",
+        "value": round(headline(main_run), 2), "unit": "x real-time (audio-sec/wall-sec); `value` = whole-job aggregate over n_gpus, `value_per_gpu` = the per-GPU figure the metric names",
+        "value_per_gpu": round(main_run["clips_slowest_rank"] * main_run["steps"] * CLIP_SECONDS / main_run["elapsed"], 2),
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * main_run["elapsed"] / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -407,6 +583,18 @@ def main():
             "fp32_leg_waveform_rms": float(ref.pow(2).mean().sqrt()),
             "labels_identical": bool(torch.equal(main_run["labels"], legs["fp32"]["labels"])),
             "gate": "north star: waveform RMS error <= 1e-3 (fp32 waveform)"}
+    if world == 1 and not a.no_config_legs:
+        # the other single-GPU configurations of BASELINE.json, each with its own roofline object; `value` above stays configs[1]
+        try:
+            res["configs4"] = leg_configs4(dev, a.encoder_dtype, a.vocoder_dtype, max(3, a.steps // 2))
+            log(f"[bench] configs4 (32 ragged clips, blind): {res['configs4']['value']} x RT, {res['configs4']['ms_per_step']} ms/step; "
+                f"sub-batches {res['configs4']['ragged_subbatches']['value']}, exact-length route {res['configs4']['exact_length_route']['value']}")
+            res.update(leg_configs3(dev, a.encoder_dtype, a.vocoder_dtype, max(3, a.steps // 2)))
+            log(f"[bench] configs3_iea_large: {res['configs3_iea_large']['value']} x RT ({res['configs3_iea_large']['ms_per_step']} ms); "
+                f"configs3_ida: {res['configs3_ida']['value']} x RT ({res['configs3_ida']['ms_per_step']} ms)")
+        except Exception as ex:
+            res["config_legs_error"] = repr(ex)
+            log(f"[bench] configs[3] / configs[4] legs failed: {ex!r}")
     if world == 1 and a.cpu_clips > 0:
         try:
             res["cpu_baseline"] = cpu_baseline(a.cpu_clips)

@@ -168,3 +168,31 @@ def extended_frames(tm: int) -> int:
     """Output width of extend_mel: floor(Tm * 441/256) (F.interpolate with scale_factor)."""
     import math
     return int(math.floor(float(tm) * (EXTEND_NUM / EXTEND_DEN)))
+
+
+def algorithmic_gmac(harch: "HubertArch", varch: "VocoderArch", n16: int, tm: int, head: bool = True, stretch: bool = True):
+    """Algorithmic multiply-accumulates (in 1e9) of one clip from layer shapes only -- SURVEY.md 8(d): conv = Cout * Cin * k * Lout,
+    convT = Cin * Cout * k * Lin, attention = 4 T H^2 + 2 T^2 H, FFN = 8 T H^2; no padding / halo / recompute.  n16 samples at
+    16 kHz, tm mel frames -> (encoder [+ head], vocoder).  4 s / 200 frames, base + V1: (28.47, 105.63) = BASELINE.md section 2."""
+    L = harch.feat_lengths(n16)
+    T = L[-1]
+    macs, cin = 0, 1
+    for i, (c, k) in enumerate(zip(harch.conv_dim, harch.conv_kernel)):
+        macs += c * cin * k * L[i + 1]
+        cin = c
+    H, I = harch.hidden_size, harch.intermediate_size
+    macs += T * cin * H + T * H * (H // harch.num_conv_pos_embedding_groups) * harch.num_conv_pos_embeddings
+    macs += harch.num_hidden_layers * (4 * T * H * H + 2 * T * T * H + 2 * T * H * I)
+    if head:
+        macs += T * H * harch.codebook_dim
+    Lr = extended_frames(tm) if stretch else tm
+    c = varch.upsample_initial_channel
+    vm = Lr * c * varch.num_mels * 7
+    for u, k in zip(varch.upsample_rates, varch.upsample_kernel_sizes):
+        vm += c * (c // 2) * k * Lr
+        c //= 2
+        Lr *= u
+        for rk, dils in zip(varch.resblock_kernel_sizes, varch.resblock_dilation_sizes):
+            vm += len(dils) * (2 if str(varch.resblock) == "1" else 1) * c * c * rk * Lr
+    vm += c * 7 * Lr
+    return macs / 1e9, vm / 1e9

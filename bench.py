@@ -365,6 +365,45 @@ def leg_configs3(dev, enc, voc, steps):
     return out
 
 
+def leg_end_to_end(dev, enc, voc, steps):
+    """SURVEY 8(f) row f-3, the request front (speech_inpainting_amd/stream.py): configs[1]'s clips start in HOST memory at the file's
+    rate (22.05 kHz float32, what `librosa.load(sr=None)` yields) and end as int16 PCM in host memory -- pinned H2D, GPU resampling to
+    16 kHz (resampy kaiser_best), masked log-mel, encoder, arg-max / splice, vocoder, int16 conversion, async D2H -- double-buffered
+    over a copy stream.  RTF includes every transfer; `value` of the main line (resident tensors) is the kernel-side figure."""
+    import numpy as np
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import InpaintingEngine
+    from speech_inpainting_amd.stream import Request, RequestFront
+    harch, varch = HubertArch.base(), VocoderArch.v1()
+    B, n22 = 32, N_SAMPLES * 22050 // 16000
+    eng = InpaintingEngine(harch, varch, 100, dev, enc, voc).load_state(synth.synth_hubert_state(harch), synth.synth_generator_state(varch),
+                                                                       synth.synth_codebook(100))
+    clips = list(synth.synth_wave(B, n22, synth.DEFAULT_SEED + 6, sr=22050).numpy())
+    pos = synth.synth_mask_frames(B, harch.num_frames(N_SAMPLES), MASK_FRAMES, synth.DEFAULT_SEED + 5).tolist()
+    rq = Request(clips, pos, MASK_FRAMES)
+    front = RequestFront(eng, 22050, depth=2)
+    for _ in front.run([rq] * 3):                                    # warm-up: buffers, resampler tables, kernels
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    for res in front.run([rq] * steps):
+        n += len(res.pcm)
+    wall = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for res in front.run([rq]):
+        pass
+    lat = time.perf_counter() - t1
+    bytes_in, bytes_out = B * n22 * 4, sum(len(p) for p in res.pcm) * 2
+    del eng
+    return {"workload": "BASELINE configs[1] from HOST clips to HOST PCM: 32 x 4 s clips at 22.05 kHz float32 in host memory -> pinned H2D -> GPU resample "
+                        "(resampy kaiser_best) -> masked log-mel -> encoder -> arg-max/splice -> vocoder -> int16 on the GPU -> async D2H; batches double-buffered",
+            "value": round(n * CLIP_SECONDS / wall, 2), "unit": "x real-time (audio-sec/wall-sec), PCIe both ways included", "ms_per_step": round(1e3 * wall / steps, 3),
+            "steps": steps, "single_batch_latency_ms": round(1e3 * lat, 3), "h2d_bytes_per_step": bytes_in, "d2h_bytes_per_step": bytes_out,
+            "dtype": f"encoder {enc}, vocoder {voc}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -403,7 +442,8 @@ def main():
 
     if a.only_config_legs:
         if rank == 0:
-            r = {"configs4": leg_configs4(dev, a.encoder_dtype, a.vocoder_dtype, max(3, a.steps // 2))}
+            r = {"configs4": leg_configs4(dev, a.encoder_dtype, a.vocoder_dtype, max(3, a.steps // 2)),
+                 "end_to_end": leg_end_to_end(dev, a.encoder_dtype, a.vocoder_dtype, max(4, a.steps))}
             r.update(leg_configs3(dev, a.encoder_dtype, a.vocoder_dtype, max(3, a.steps // 2)))
             print(json.dumps(r), flush=True)
         return
@@ -589,6 +629,9 @@ def main():
             res["configs4"] = leg_configs4(dev, a.encoder_dtype, a.vocoder_dtype, max(3, a.steps // 2))
             log(f"[bench] configs4 (32 ragged clips, blind): {res['configs4']['value']} x RT, {res['configs4']['ms_per_step']} ms/step; "
                 f"sub-batches {res['configs4']['ragged_subbatches']['value']}, exact-length route {res['configs4']['exact_length_route']['value']}")
+            res["end_to_end"] = leg_end_to_end(dev, a.encoder_dtype, a.vocoder_dtype, max(4, a.steps))
+            log(f"[bench] end_to_end (host clips -> host PCM, double-buffered): {res['end_to_end']['value']} x RT, {res['end_to_end']['ms_per_step']} ms/step, "
+                f"single-batch latency {res['end_to_end']['single_batch_latency_ms']} ms")
             res.update(leg_configs3(dev, a.encoder_dtype, a.vocoder_dtype, max(3, a.steps // 2)))
             log(f"[bench] configs3_iea_large: {res['configs3_iea_large']['value']} x RT ({res['configs3_iea_large']['ms_per_step']} ms); "
                 f"configs3_ida: {res['configs3_ida']['value']} x RT ({res['configs3_ida']['ms_per_step']} ms)")

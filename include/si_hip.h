@@ -289,6 +289,33 @@ int si_f0_encoder_forward(si_ctx* ctx, const si_f0enc_desc* d, const float* weig
 int si_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const float* taps, int ntaps, int up, int down,
                      int pre_remove, int n_out, float* y, si_stream_t stream);
 
+/* librosa's OWN resampler: `librosa.load(path, sr=16000)` at I_ea/predict.py:79-80 is, in the pinned
+ * librosa==0.9.1 (requirements.txt:3), `resample(..., res_type='kaiser_best')` = resampy's band-limited interpolation with its
+ * `kaiser_best` table.  resampy is a third-party dependency absent from the build image (no version pinned by the reference); its
+ * published algorithm is restated (oracle/ref_cpu.py::resample_kaiser_best) and pinned bit for bit by the fixture the reference
+ * holds: I_ea/hifi_gan/test_files/LJ001-0001_{22k,16k}.wav (tests/golden/lj001_resample.npz).
+ * The caller designs the tables on the host (speech_inpainting_amd/audio.py::design_kaiser_best) and owns them on the device:
+ * win / dwin float64 (nwin): the windowed sinc's right wing (scaled by the ratio when down-sampling) and its forward differences;
+ * time_reg float64 (n_time): output sample t's input time, 1 / ratio accumulated by repeated addition as resampy's loop does.
+ * x (B, n_in) fp32; n_len device int32 (B) or NULL: ragged batches, clip b holds n_len[b] samples; y (B, n_out) fp32: samples
+ * >= int(len_b * ratio) are zero (librosa's fix_length padding up to ceil(len * ratio)). */
+typedef struct si_sinc_filter {
+    int32_t struct_size;        /* = sizeof(si_sinc_filter) */
+    int32_t nwin, num_table, step, n_time;
+    int32_t reserved;
+    double scale, ratio;
+    const double* win;
+    const double* dwin;
+    const double* time_reg;
+} si_sinc_filter;
+int si_resample_sinc(si_ctx* ctx, const float* x, const int32_t* n_len, int B, int n_in, const si_sinc_filter* f, int n_out, float* y,
+                     si_stream_t stream);
+
+/* B6 on the device (I_ea/predict.py:204-206: `audio * 32768`, `.astype('int16')`): out[i] = the fp32 product truncated toward
+ * zero; 32768.0 (an exactly saturated +1.0 sample, where the reference's cast is undefined behaviour) gives 32767, NaN gives 0.
+ * wav device fp32 (n), out device int16 (n). */
+int si_pcm16(si_ctx* ctx, const float* wav, int64_t n, int16_t* out, si_stream_t stream);
+
 /* Vocoder: mel (B, D, Tm) -> time-stretch x441/256 -> generator -> wav_out (B, floor(Tm*441/256) * hop).
  * stretch = 0 skips extend_mel (mel already at the generator's frame rate; output (B, Tm * hop)). */
 int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch, float* wav_out,

@@ -102,6 +102,88 @@ def masked_mel(wave22, mask_start: Optional[Sequence[int]], mask_end: Optional[S
     return mel_spectrogram(torch.from_numpy(np.stack(clips)))
 
 
+# ----------------------------------------------------------------------------- f-3 (sample-rate conversion in front of the path)
+KAISER_BEST = dict(num_zeros=64, precision=9, rolloff=0.9475937167399596, beta=14.769656459379492)
+
+
+def kaiser_best_window():
+    """The `kaiser_best` interpolation filter of resampy -- the resampler behind `librosa.load(path, sr=16000)` at
+    I_ea/predict.py:79-80 (librosa==0.9.1, requirements.txt:3: `resample(..., res_type='kaiser_best')` -> `resampy.resample`).
+    resampy is NOT in this image and the reference pins no version of it; its published design, restated: the right wing of a
+    Kaiser-windowed sinc, `rolloff * sinc(rolloff * t)` on t in [0, num_zeros] sampled 2^precision times per zero crossing,
+    tapered by the right half of `kaiser(2 n + 1, beta)` (resampy.filters.sinc_window with the kaiser_best parameters: 64 zero
+    crossings, precision 9, roll-off 0.9475937167399596, beta 14.769656459379492).  -> (float64 window (32769,), 512)."""
+    import numpy as np
+    from scipy.signal.windows import kaiser
+    nb = 2 ** KAISER_BEST["precision"]
+    n = nb * KAISER_BEST["num_zeros"]
+    r = KAISER_BEST["rolloff"]
+    sinc_win = r * np.sinc(r * np.linspace(0, KAISER_BEST["num_zeros"], num=n + 1, endpoint=True))
+    return kaiser(2 * n + 1, KAISER_BEST["beta"])[n:] * sinc_win, nb
+
+
+def resample_time_registers(n_out: int, sr_in: int, sr_out: int):
+    """resampy's `time_register` for output samples 0 .. n_out - 1: built by REPEATED ADDITION of 1 / ratio in float64, exactly as
+    the loop does.  Where the exact time is an integer (every 320th output sample for 22.05 -> 16 kHz) the accumulated rounding
+    decides between (n, frac = scale (1 - eps)) and (n + 1, frac = 0), and because the table step is truncated to an integer
+    (371 for 371.52) the two give DIFFERENT samples (up to 8 LSB of int16 on speech): bit-faithfulness needs this very sequence."""
+    import numpy as np
+    tr = np.cumsum(np.full(max(int(n_out), 1), 1.0 / (float(sr_out) / float(sr_in)))) - 1.0 / (float(sr_out) / float(sr_in))
+    tr[0] = 0.0
+    return tr[:max(int(n_out), 0)]
+
+
+def resample_kaiser_best(x, sr_in: int, sr_out: int, fix_length: bool = True, first_output: int = 0, first_input: int = 0):
+    """`librosa.resample(x, orig_sr, target_sr, res_type='kaiser_best')` of librosa 0.9.1 for a 1-D float clip -- what
+    `librosa.load(path, sr=target)` applies to the file's samples (I_ea/predict.py:79-80; also I_ea/metrics.py:82,107).
+    resampy's band-limited interpolation loop (resampy/interpn.py `resample_f`), restated per output sample t:
+        time = t / ratio (accumulated by repeated addition in the original);  n = int(time);  frac = scale * (time - n)
+        left wing : sum_i (win[off + i step] + eta * dwin[off + i step]) * x[n - i],       off, eta = split(frac * 512)
+        right wing: sum_k (win[off' + k step] + eta' * dwin[...]) * x[n + 1 + k],          off', eta' = split((scale - frac) * 512)
+    with scale = min(1, ratio), step = int(scale * 512), win scaled by ratio when down-sampling, dwin = forward differences;
+    n_out = int(n_in * ratio), then librosa pads with zeros to ceil(n_in * ratio) (`util.fix_length`).
+    first_output / first_input: `x` is the excerpt x_full[first_input:] of a longer clip and the outputs wanted are samples
+    first_output, first_output + 1, ... of the WHOLE clip's conversion (same time registers; taps before the excerpt are missing).
+    PINNED by a fixture the reference itself holds: I_ea/hifi_gan/test_files/LJ001-0001_{22k,16k}.wav are one utterance at both
+    rates, and floor(32768 * this function(22k file)) equals the 16k file on 154 479 of its 154 480 samples, the other within one
+    LSB (tests/test_oracle_golden.py, tests/golden/lj001_resample.npz).  float64 numpy in and out."""
+    import numpy as np
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    ratio = float(sr_out) / float(sr_in)
+    n_in = x.shape[0]
+    n_out = int((n_in + first_input) * ratio) - first_output
+    win, num_table = kaiser_best_window()
+    win = win.copy()
+    if ratio < 1:
+        win *= ratio
+    delta = np.zeros_like(win)
+    delta[:-1] = np.diff(win)
+    scale = min(1.0, ratio)
+    step = int(scale * num_table)
+    nwin = win.shape[0]
+    tr = resample_time_registers(n_out + first_output, sr_in, sr_out)[first_output:] - first_input   # (an integer shift: exact)
+    y = np.zeros(n_out)
+    taps = np.arange(nwin // step + 2)[None, :]
+    for t0 in range(0, n_out, 8192):
+        t = np.arange(t0, min(n_out, t0 + 8192))
+        n = np.floor(tr[t]).astype(np.int64)
+        frac = scale * (tr[t] - n)
+        for wing in (0, 1):
+            f = frac if wing == 0 else scale - frac
+            idx = f * num_table
+            off = idx.astype(np.int64)
+            eta = idx - off
+            cnt = np.minimum(n + 1 if wing == 0 else n_in - n - 1, (nwin - off) // step)[:, None]
+            ok = taps < cnt
+            wi = np.where(ok, off[:, None] + taps * step, 0)
+            xi = np.where(ok, n[:, None] - taps if wing == 0 else n[:, None] + taps + 1, 0)
+            y[t] += (((win[wi] + eta[:, None] * delta[wi]) * ok) * x[xi]).sum(1)
+    if fix_length and first_output == 0 and first_input == 0:
+        full = int(math.ceil(n_in * ratio))
+        y = np.concatenate([y, np.zeros(max(full - n_out, 0))])[:full]
+    return y
+
+
 # ----------------------------------------------------------------------------- A0
 def mask_and_normalize(wave: torch.Tensor, mask_start: Sequence[int], mask_len: Sequence[int]) -> torch.Tensor:
     """A0.  Zero samples [start, start+len) of each clip (I_ea/predict.py:132-133), then the HF processor's

@@ -54,6 +54,36 @@ def design_resampler(sr_in: int, sr_out: int, n_in: int):
     return taps, up, down, n_pre_remove, n_out
 
 
+KAISER_BEST = dict(num_zeros=64, precision=9, rolloff=0.9475937167399596, beta=KAISER_BETA)
+
+
+def design_kaiser_best(sr_in: int, sr_out: int, n_in: int):
+    """Tables of resampy's `kaiser_best` band-limited interpolation -- the resampler behind `librosa.load(path, sr=...)` in the
+    reference's pinned librosa==0.9.1 (I_ea/predict.py:79-80; requirements.txt:3) -- for the GPU kernel (si_resample_sinc):
+    win = rolloff * sinc(rolloff * t), t in [0, 64] at 512 samples per zero crossing, tapered by the right half of a Kaiser window
+    (beta 14.77), scaled by the ratio when down-sampling; dwin = its forward differences; time_reg[t] = output sample t's input time,
+    1 / ratio accumulated by REPEATED ADDITION in float64 as resampy's loop does (at exactly-integer times the accumulated rounding
+    selects the table phase, and the phases differ because the table step is truncated to an integer).
+    -> dict(win, dwin, time_reg float64 numpy; num_table, step, scale, ratio, n_out = ceil(n_in * ratio) (librosa's fix_length))."""
+    from scipy.signal.windows import kaiser
+    ratio = float(sr_out) / float(sr_in)
+    nb = 2 ** KAISER_BEST["precision"]
+    n = nb * KAISER_BEST["num_zeros"]
+    r = KAISER_BEST["rolloff"]
+    win = kaiser(2 * n + 1, KAISER_BEST["beta"])[n:] * (r * np.sinc(r * np.linspace(0, KAISER_BEST["num_zeros"], num=n + 1, endpoint=True)))
+    if ratio < 1:
+        win = win * ratio
+    dwin = np.zeros_like(win)
+    dwin[:-1] = np.diff(win)
+    scale = min(1.0, ratio)
+    n_out = int(math.ceil(n_in * ratio))
+    inc = 1.0 / ratio
+    tr = np.cumsum(np.full(max(n_out, 1), inc)) - inc
+    tr[0] = 0.0
+    return dict(win=np.ascontiguousarray(win), dwin=dwin, time_reg=tr[:n_out].copy(), num_table=nb, step=int(scale * nb), scale=scale,
+                ratio=ratio, n_out=n_out)
+
+
 def resample(x: np.ndarray, sr_in: int, sr_out: int) -> np.ndarray:
     """Host (scipy) resampler with the same filter: the reference of the GPU one in the tests; predict.py resamples on
     the GPU (InpaintingEngine.resample)."""

@@ -1217,6 +1217,24 @@ int si_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const float* 
 static int hifigan_run(si_ctx* ctx, const float* mel, int B, int Tm, int stretch, float* wav_out, void* workspace,
                        size_t workspace_bytes, si_stream_t stream, const int32_t* host_len);
 
+int si_resample_sinc(si_ctx* ctx, const float* x, const int32_t* n_len, int B, int n_in, const si_sinc_filter* f, int n_out, float* y,
+                     si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!x || !y || !f || !f->win || !f->dwin || !f->time_reg || B <= 0 || n_in <= 0) return si_fail(ctx, SI_EINVAL, "si_resample_sinc: NULL / empty argument");
+    if (f->struct_size != (int32_t)sizeof(si_sinc_filter)) return si_fail(ctx, SI_EINVAL, "si_resample_sinc: si_sinc_filter size mismatch");
+    if (n_out > f->n_time) return si_fail(ctx, SI_EINVAL, "si_resample_sinc: %d outputs but the time-register table holds %d", n_out, f->n_time);
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    return si_launch_resample_sinc(ctx, x, n_len, B, n_in, f->win, f->dwin, f->nwin, f->num_table, f->step, f->scale, f->ratio, f->time_reg, n_out, y,
+                                   static_cast<hipStream_t>(stream));
+}
+
+int si_pcm16(si_ctx* ctx, const float* wav, int64_t n, int16_t* out, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!wav || !out || n < 0) return si_fail(ctx, SI_EINVAL, "si_pcm16: NULL / bad argument");
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    return si_launch_pcm16(ctx, wav, (long)n, out, static_cast<hipStream_t>(stream));
+}
+
 int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch, float* wav_out, void* workspace,
                        size_t workspace_bytes, si_stream_t stream) {
     return hifigan_run(ctx, mel, B, Tm, stretch, wav_out, workspace, workspace_bytes, stream, nullptr);

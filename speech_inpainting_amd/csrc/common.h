@@ -257,6 +257,12 @@ int si_launch_mel_project(si_ctx* ctx, const float* spec, int ld_spec, int nbin,
 int si_launch_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const float* taps, int ntaps, int up, int down,
                             int pre_remove, int n_out, float* y, hipStream_t st);
 
+// resampy / librosa 0.9.1 `kaiser_best` band-limited interpolation (frontend_kernels.hip); tables are device float64
+int si_launch_resample_sinc(si_ctx* ctx, const float* x, const int32_t* n_len, int B, int n_in, const double* win, const double* dwin, int nwin,
+                            int num_table, int step, double scale, double ratio, const double* time_reg, int n_out, float* y, hipStream_t st);
+// `audio * 32768` + truncating int16 cast (I_ea/predict.py:204-206)
+int si_launch_pcm16(si_ctx* ctx, const float* wav, long n, int16_t* out, hipStream_t st);
+
 // erf-GELU of the bf16 encoder's GEMM epilogues (lingemm.hip, gemm256.hip: the SAME function, their results are bit-identical).
 // erf by Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 -- below one fp32 ulp of the result for |x| >= 1 and far below the bf16
 // rounding every consumer of these outputs applies; 15 VALU operations instead of libm erff's ~31 with two divergent branches.

@@ -186,3 +186,103 @@ int si_launch_resample_poly(si_ctx* ctx, const float* x, int B, int n_in, const 
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ f-3: librosa's resampler
+// `librosa.load(path, sr=16000)` of librosa 0.9.1 (I_ea/predict.py:79-80; requirements.txt:3) resamples with resampy's `kaiser_best`
+// filter: band-limited interpolation with a table of the windowed sinc's right wing (512 samples per zero crossing, 64 zero
+// crossings) and linear interpolation between table entries.  Per output sample t (resampy/interpn.py):
+//     time = time_register[t] (1 / ratio accumulated by repeated addition in float64 -- the HOST builds that very sequence, because
+//            where the exact time is an integer its rounding picks between two table phases that give different samples);
+//     n = int(time);  frac = scale * (time - n);  off, eta = split(frac * num_table)
+//     y[t]  = sum_{i < min(n + 1, (nwin - off) / step)}         (win[off + i step] + eta dwin[off + i step]) * x[n - i]
+//           + sum_{k < min(n_in - n - 1, (nwin - off') / step)}  (win[off' + k step] + eta' dwin[...])       * x[n + 1 + k],   off', eta' from scale - frac
+// for t < int(n_in * ratio); librosa then pads with zeros (util.fix_length).  Weights and sums in float64 (the tables are float64):
+// the result reproduces the reference-held 16 kHz rendering of LJ001-0001 bit for bit after its int16 quantisation.
+// One thread per output sample; the 0.5 MB of tables sit in L2 and the 64 lanes of a load share ~24 cache lines (their phases fall
+// inside one `step` of the table).  (A phase-major copy of the table -- a thread's taps consecutive in memory -- was measured: 2.9 ms
+// instead of 0.92 per 32 x 4 s: every lane then owns its own lines.)  n_len (B) or null: ragged batches, clip b holds n_len[b] samples.
+__global__ __launch_bounds__(256) void resample_sinc_kernel(const float* __restrict__ x, const int32_t* __restrict__ n_len, int n_in_stride,
+                                                            const double* __restrict__ win, const double* __restrict__ dwin, int nwin,
+                                                            int num_table, int step, double scale, double ratio,
+                                                            const double* __restrict__ time_reg, int n_out_stride, float* __restrict__ y) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_out_stride) return;
+    const int n_in = n_len ? n_len[b] : n_in_stride;
+    const int n_out = (int)((double)n_in * ratio);
+    float* yo = y + (long)b * n_out_stride + t;
+    if (t >= n_out) { *yo = 0.f; return; }
+    const float* xb = x + (long)b * n_in_stride;
+    const double time = time_reg[t];
+    const int n = (int)time;
+    double frac = scale * (time - n);
+    double acc = 0.0;
+    {
+        const double idx = frac * num_table;
+        const int off = (int)idx;
+        const double eta = idx - off;
+        const int cnt = min(n + 1, (nwin - off) / step);
+        for (int i = 0; i < cnt; ++i) {
+            const int w = off + i * step;
+            acc += (win[w] + eta * dwin[w]) * (double)xb[n - i];
+        }
+    }
+    {
+        frac = scale - frac;
+        const double idx = frac * num_table;
+        const int off = (int)idx;
+        const double eta = idx - off;
+        const int cnt = min(n_in - n - 1, (nwin - off) / step);
+        for (int k = 0; k < cnt; ++k) {
+            const int w = off + k * step;
+            acc += (win[w] + eta * dwin[w]) * (double)xb[n + k + 1];
+        }
+    }
+    *yo = (float)acc;
+}
+
+int si_launch_resample_sinc(si_ctx* ctx, const float* x, const int32_t* n_len, int B, int n_in, const double* win, const double* dwin, int nwin,
+                            int num_table, int step, double scale, double ratio, const double* time_reg, int n_out, float* y, hipStream_t st) {
+    if (nwin < 2 || num_table < 1 || step < 1 || !(scale > 0.0) || !(ratio > 0.0))
+        return si_fail(ctx, SI_EINVAL, "resample_sinc: bad filter table (nwin %d, num_table %d, step %d)", nwin, num_table, step);
+    if (B <= 0 || n_out <= 0) return SI_OK;
+    si_prof_begin(ctx, "resample_sinc", 4.0 * B * n_out * (2.0 * nwin / step), 4.0 * B * ((double)n_in + n_out), st);
+    hipLaunchKernelGGL(resample_sinc_kernel, dim3((n_out + 255) / 256, B), dim3(256), 0, st, x, n_len, n_in, win, dwin, nwin, num_table, step, scale, ratio,
+                       time_reg, n_out, y);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ B6: int16 PCM
+// The script's `audio * MAX_WAV_VALUE` + `.astype('int16')` (I_ea/predict.py:204-206): the fp32 product truncated toward zero.  The
+// generator ends in tanh, so the product lies in [-32768, 32768]; 32768.0 (an exactly saturated sample) is outside int16, where the
+// reference's cast is undefined behaviour: pinned to 32767 (audio.to_int16_pcm does the same on the host).  NaN -> 0.
+__global__ __launch_bounds__(256) void pcm16_kernel(const float* __restrict__ wav, long n, int16_t* __restrict__ out) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n && (reinterpret_cast<size_t>(wav) & 15) == 0 && (reinterpret_cast<size_t>(out) & 7) == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(wav + i);
+        const float q[4] = {v.x, v.y, v.z, v.w};
+        short r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float p = q[e] * 32768.0f;
+            r[e] = (short)(int)fminf(fmaxf(truncf(p == p ? p : 0.f), -32768.f), 32767.f);
+        }
+        *reinterpret_cast<short4*>(out + i) = make_short4(r[0], r[1], r[2], r[3]);
+        return;
+    }
+    for (long j = i; j < n && j < i + 4; ++j) {
+        const float p = wav[j] * 32768.0f;
+        out[j] = (int16_t)(int)fminf(fmaxf(truncf(p == p ? p : 0.f), -32768.f), 32767.f);
+    }
+}
+
+int si_launch_pcm16(si_ctx* ctx, const float* wav, long n, int16_t* out, hipStream_t st) {
+    if (n <= 0) return SI_OK;
+    si_prof_begin(ctx, "pcm16", (double)n, 6.0 * n, st);
+    hipLaunchKernelGGL(pcm16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, wav, n, out);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}

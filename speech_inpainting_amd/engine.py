@@ -174,18 +174,38 @@ class InpaintingEngine:
         peak-normalise * 0.95, log-mel -> (B, 80, Tm)."""
         return self.ctx.mel_frontend(wave22, mask_start, mask_end, normalize)
 
-    def resample(self, x: torch.Tensor, sr_in: int, sr_out: int) -> torch.Tensor:
-        """(B, n) fp32 clips at sr_in -> (B, ceil(n * sr_out / sr_in)) at sr_out on the GPU (polyphase Kaiser FIR, the
-        arithmetic of scipy.signal.resample_poly; stands in for librosa.load(..., sr=...) at I_ea/predict.py:79-80)."""
+    def resample(self, x: torch.Tensor, sr_in: int, sr_out: int, kind: str = "kaiser_best", lens=None) -> torch.Tensor:
+        """(B, n) fp32 clips at sr_in -> (B, ceil(n * sr_out / sr_in)) at sr_out on the GPU: `librosa.load(..., sr=...)`'s resampling
+        (I_ea/predict.py:79-80).  kind="kaiser_best" (default): resampy's band-limited interpolation, what librosa 0.9.1 runs --
+        pinned bit for bit by the reference-held LJ001-0001 22k / 16k pair (si_resample_sinc).  kind="poly": the polyphase Kaiser
+        FIR with scipy.signal.resample_poly's arithmetic (si_resample_poly; a different filter).  lens: per-clip sample counts of a
+        ragged batch (kaiser_best only): clip b's output is zero past int(lens[b] * ratio)."""
         from . import audio
         if sr_in == sr_out:
             return x.clone()
-        key = (int(sr_in), int(sr_out), int(x.shape[1]))
+        key = (kind, int(sr_in), int(sr_out), int(x.shape[1]))
+        if kind == "kaiser_best":
+            if key not in self._resamplers:
+                f = audio.design_kaiser_best(sr_in, sr_out, x.shape[1])
+                for k in ("win", "dwin", "time_reg"):
+                    f[k] = torch.from_numpy(f[k]).to(self.device)
+                self._resamplers[key] = f
+            f = self._resamplers[key]
+            n_len = None if lens is None else torch.as_tensor(list(lens), dtype=torch.int32).to(self.device)
+            return self.ctx.resample_sinc(x.contiguous(), f, f["n_out"], n_len)
+        if kind != "poly":
+            raise ValueError(f"resample kind {kind!r}: 'kaiser_best' or 'poly'")
+        if lens is not None:
+            raise ValueError("ragged batches are resampled with kind='kaiser_best'")
         if key not in self._resamplers:
             taps, up, down, pre, n_out = audio.design_resampler(sr_in, sr_out, x.shape[1])
             self._resamplers[key] = (torch.from_numpy(taps).to(self.device), up, down, pre, n_out)
         taps, up, down, pre, n_out = self._resamplers[key]
         return self.ctx.resample_poly(x.contiguous(), taps, up, down, pre, n_out)
+
+    def to_int16(self, wave: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """B6 on the GPU (I_ea/predict.py:204-206): fp32 waveform -> int16 PCM, `* 32768` truncated toward zero (si_pcm16)."""
+        return self.ctx.pcm16(wave.contiguous(), out)
 
     def get_mel(self, x: torch.Tensor) -> torch.Tensor:
         """`get_mel(x)` of I_ea/dataset/mel_dump.py:96-98: x (B, n) already normalised -> (B, 80, Tm) log-mel."""

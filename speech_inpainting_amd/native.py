@@ -25,7 +25,7 @@ EXPORTS = ["si_version", "si_create", "si_destroy", "si_last_error", "si_load_we
            "si_codebook_splice_varlen", "si_hifigan_forward_varlen", "si_mel_frontend_varlen",
            "si_codebook_splice_labels", "si_codebook_metrics", "si_kmeans_assign", "si_mel_metrics", "si_sisdr", "si_unit_frontend",
            "si_f0_encoder_weight_floats", "si_f0_encoder_frames", "si_f0_encoder_workspace_bytes", "si_f0_encoder_forward",
-           "si_resample_poly", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
+           "si_resample_poly", "si_resample_sinc", "si_pcm16", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
            "si_vocoder_samples", "si_profile_start", "si_profile_filter", "si_profile_stop",
            "si_debug_capture", "si_debug_size"]
 
@@ -49,6 +49,13 @@ class F0EncDesc:
     def down_kernel(self):
         s = self.stride_t
         return (2 * s, s // 2) if s % 2 == 0 else (2 * s + 1, s // 2 + 1)          # jukebox.py:54-57
+
+
+class SincFilter(C.Structure):
+    """Mirror of si_sinc_filter."""
+    _fields_ = [("struct_size", C.c_int32), ("nwin", C.c_int32), ("num_table", C.c_int32), ("step", C.c_int32), ("n_time", C.c_int32),
+                ("reserved", C.c_int32), ("scale", C.c_double), ("ratio", C.c_double), ("win", C.c_void_p), ("dwin", C.c_void_p),
+                ("time_reg", C.c_void_p)]
 
 
 class ExtractDesc(C.Structure):
@@ -178,6 +185,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.si_f0_encoder_workspace_bytes.restype = C.c_size_t
     lib.si_f0_encoder_forward.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, C.c_size_t, vp]
     lib.si_resample_poly.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.si_resample_sinc.argtypes = [vp, vp, vp, i32, i32, C.POINTER(SincFilter), i32, vp, vp]
+    lib.si_pcm16.argtypes = [vp, vp, C.c_int64, vp, vp]
     lib.si_hifigan_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_mel_frames.argtypes = [i32]
     lib.si_mel_workspace_bytes.argtypes = [vp, i32, i32, C.POINTER(sz)]
@@ -549,6 +558,29 @@ class NativeContext:
         self._check(self.lib.si_resample_poly(self._h, _ptr(x), x.shape[0], x.shape[1], _ptr(taps), taps.numel(), int(up), int(down),
                                               int(pre_remove), int(n_out), _ptr(y), self._stream()), "si_resample_poly")
         return y
+
+    def resample_sinc(self, x: torch.Tensor, filt: dict, n_out: int, n_len: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x (B, n_in) -> (B, n_out) by resampy's `kaiser_best` interpolation (librosa 0.9.1's resampler); `filt` holds the DEVICE
+        tables of audio.design_kaiser_best (win, dwin, time_reg float64) and its scalars; n_len (B,) int32 device lengths or None."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+        for k in ("win", "dwin", "time_reg"):
+            assert filt[k].is_cuda and filt[k].dtype == torch.float64 and filt[k].is_contiguous()
+        assert n_len is None or (n_len.is_cuda and n_len.dtype == torch.int32 and n_len.numel() == x.shape[0] and n_len.is_contiguous())
+        f = SincFilter(C.sizeof(SincFilter), filt["win"].numel(), int(filt["num_table"]), int(filt["step"]), filt["time_reg"].numel(), 0,
+                       float(filt["scale"]), float(filt["ratio"]), filt["win"].data_ptr(), filt["dwin"].data_ptr(), filt["time_reg"].data_ptr())
+        y = torch.empty(x.shape[0], int(n_out), dtype=torch.float32, device=self.device)
+        self._check(self.lib.si_resample_sinc(self._h, _ptr(x), _ptr(n_len), x.shape[0], x.shape[1], C.byref(f), int(n_out), _ptr(y), self._stream()),
+                    "si_resample_sinc")
+        return y
+
+    def pcm16(self, wav: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """fp32 waveform (any shape) -> int16 PCM on the device: `audio * 32768` truncated toward zero (I_ea/predict.py:204-206)."""
+        assert wav.is_cuda and wav.dtype == torch.float32 and wav.is_contiguous()
+        if out is None:
+            out = torch.empty(wav.shape, dtype=torch.int16, device=self.device)
+        assert out.is_cuda and out.dtype == torch.int16 and out.is_contiguous() and out.numel() == wav.numel()
+        self._check(self.lib.si_pcm16(self._h, _ptr(wav), wav.numel(), _ptr(out), self._stream()), "si_pcm16")
+        return out
 
     def hifigan_forward(self, mel: torch.Tensor, stretch: bool = True) -> torch.Tensor:
         assert mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous() and mel.dim() == 3

@@ -10,8 +10,9 @@ It reads the reference's YAML schema, loads the same three artefacts (CustomMode
 `expected_inpaint.wav` only when the ground-truth label file exists).  `predict_clips` is the importable batch form.
 
 Differences from the script, all outside the three replaced subsystems: no Whisper `Metrics` object is built (the
-script constructs it and never uses it, I_ea/predict.py:72-73), PNG plots are skipped, and audio loading / resampling
-uses a polyphase Kaiser FIR on the GPU (si_resample_poly; scipy's resample_poly arithmetic) instead of librosa.
+script constructs it and never uses it, I_ea/predict.py:72-73), PNG plots are skipped, and the two `librosa.load` calls are one
+wav read plus the resampler librosa 0.9.1 itself uses (resampy `kaiser_best`) run on the GPU (si_resample_sinc; pinned against the
+reference-held LJ001-0001 22k / 16k pair), the clips staying on the device from there to the int16 conversion (si_pcm16).
 """
 from __future__ import annotations
 
@@ -70,11 +71,22 @@ def predict_clips(engine: InpaintingEngine, waves16: Sequence[np.ndarray], waves
     dev = engine.device
     n16, n22 = len(waves16[0]), len(waves22[0])
     if any(len(w) != n16 for w in waves16) or any(len(w) != n22 for w in waves22):
-        raise ValueError("clips in one batch must have equal length (group by exact length; HuBERT-base's GroupNorm "
-                         "is not padding-invariant)")
+        raise ValueError("clips in one batch must have equal length (predict_clips_ragged / predict_ragged take clips of "
+                         "different lengths)")
+    wave22 = torch.from_numpy(np.stack([np.asarray(w, dtype=np.float32) for w in waves22])).to(dev)
+    wave = torch.from_numpy(np.stack([np.asarray(w, dtype=np.float32) for w in waves16])).to(dev)
+    return predict_resident(engine, wave, wave22, mask_pos, mask_frames, blind, mask22, diagnostics, target_labels)
+
+
+def predict_resident(engine: InpaintingEngine, wave: torch.Tensor, wave22: torch.Tensor, mask_pos: Sequence[int], mask_frames: int,
+                     blind: bool = False, mask22: Optional[Sequence[Tuple[int, int]]] = None, diagnostics: bool = False,
+                     target_labels: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """`predict_clips` on clips that are already on the GPU: wave (B, n16) / wave22 (B, n22) float32 device tensors (e.g. straight
+    out of `engine.resample`); same outputs."""
+    dev = engine.device
+    n16, n22 = wave.shape[1], wave22.shape[1]
     if not blind:
         check_mask_span(engine, n16, n22, mask_pos, mask_frames)
-    wave22 = torch.from_numpy(np.stack([np.asarray(w, dtype=np.float32) for w in waves22])).to(dev)
     if blind:
         mel = engine.mel(wave22)                                                    # nothing zeroed; predict.py:104-106
     else:
@@ -83,7 +95,6 @@ def predict_clips(engine: InpaintingEngine, waves16: Sequence[np.ndarray], waves
         s22 = torch.tensor([min(max(int(a), 0), n22) for a, _ in mask22], dtype=torch.int32, device=dev)
         e22 = torch.tensor([min(max(int(b), 0), n22) for _, b in mask22], dtype=torch.int32, device=dev)
         mel = engine.mel(wave22, s22, e22)                                          # predict.py:99-106 on the GPU
-    wave = torch.from_numpy(np.stack([np.asarray(w, dtype=np.float32) for w in waves16])).to(dev)
     pos = torch.tensor(list(mask_pos), dtype=torch.int32, device=dev)
     out = engine.predict_batch(wave, mel, pos, mask_frames, blind=blind)
     out["mel_masked"] = mel
@@ -219,32 +230,33 @@ def main(argv=None) -> int:
     wave_name = cfg.wave_path.split("/")[-1].split(".")[0]
     save_dir = os.path.join(cfg.save_pred, wave_name)
     os.makedirs(save_dir, exist_ok=True)
-    raw, sr_file = audio.read_wav(cfg.wave_path)                                   # predict.py:79-80 (librosa.load x 2):
-    raw_dev = torch.from_numpy(raw)[None].to(engine.device)                        # one read, both rates on the GPU
-    wave_22 = engine.resample(raw_dev, sr_file, 22050)[0].cpu().numpy()
-    wave_16 = engine.resample(raw_dev, sr_file, 16000)[0].cpu().numpy()
-    audio.write_wav(os.path.join(save_dir, "orig.wav"), wave_16, 16000)
+    raw, sr_file = audio.read_wav(cfg.wave_path)                                   # predict.py:79-80 (librosa.load x 2): one read,
+    raw_dev = torch.from_numpy(raw)[None].to(engine.device)                        # both rates on the GPU with librosa 0.9.1's own
+    wave_22 = engine.resample(raw_dev, sr_file, 22050)                             # resampler (resampy kaiser_best); they STAY there
+    wave_16 = engine.resample(raw_dev, sr_file, 16000)
+    audio.write_wav(os.path.join(save_dir, "orig.wav"), wave_16[0].cpu().numpy(), 16000)
     pos, lm = cfg.mask_pos, cfg.mask_frames
-    masked_16 = wave_16.copy()
+    masked_16 = wave_16[0].clone()
     masked_16[pos * 320 + 80:(pos + lm) * 320 + 79 - 80] = 0                       # predict.py:133
-    audio.write_wav(os.path.join(save_dir, "masked.wav"), masked_16, 16000)
+    audio.write_wav(os.path.join(save_dir, "masked.wav"), masked_16.cpu().numpy(), 16000)
 
     span22 = (cfg.start_sample * 22050 // 16000, cfg.end_sample * 22050 // 16000)   # predict.py:99-100
     labels_path = os.path.join(cfg.path2centroids, wave_name + "_labels.pt")
     labels = None
     if os.path.exists(labels_path):                                                # predict.py:160-161
         labels = torch.load(labels_path, map_location="cpu").t().reshape(-1)[pos:pos + lm].long()
-    out = predict_clips(engine, [wave_16], [wave_22], [pos], lm, mask22=[span22], diagnostics=True,
-                        target_labels=None if labels is None else labels[None])
+    out = predict_resident(engine, wave_16, wave_22, [pos], lm, mask22=[span22], diagnostics=True,
+                           target_labels=None if labels is None else labels[None])
+    pcm = lambda w: engine.to_int16(w[0]).cpu().numpy()                            # predict.py:204-206 on the GPU (si_pcm16)
     # hifi_masked.wav: the vocoder on the masked mel alone (predict.py:123-128)
-    audio.write_wav(os.path.join(save_dir, "hifi_masked.wav"), audio.to_int16_pcm(out["hifi_masked"][0]), 22050)
+    audio.write_wav(os.path.join(save_dir, "hifi_masked.wav"), pcm(out["hifi_masked"]), 22050)
     if labels is not None:                                                         # predict.py:171-189,198-201
-        audio.write_wav(os.path.join(save_dir, "expected_inpaint.wav"), audio.to_int16_pcm(out["expected_inpaint"][0]), 22050)
+        audio.write_wav(os.path.join(save_dir, "expected_inpaint.wav"), pcm(out["expected_inpaint"]), 22050)
         print("Loss:", float(out["loss"]))
         print("Average Cosine Similarity: ", float(out["cos_pred_target"].mean()))
         print("Target codewords: ", labels.tolist())
     print("Predicted codewords: ", out["labels"][0].tolist())
-    audio.write_wav(os.path.join(save_dir, "inpainted.wav"), audio.to_int16_pcm(out["wave"][0]), 22050)
+    audio.write_wav(os.path.join(save_dir, "inpainted.wav"), pcm(out["wave"]), 22050)
     print("wrote", save_dir)
     return 0
 

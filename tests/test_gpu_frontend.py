@@ -131,3 +131,49 @@ def test_gpu_resampler_matches_scipy_resample_poly(ctx):
         err = np.abs(got - ref).max()
         assert err <= 2e-6 * max(1.0, np.abs(ref).max()), (sr_in, sr_out, n, err)
         assert np.allclose(audio.resample(x[0], sr_in, sr_out), got[0], atol=3e-6)          # the host helper agrees too
+
+
+def test_gpu_kaiser_best_resampler_reproduces_the_reference_held_16k_file(ctx):
+    """f-3, pinned: si_resample_sinc (resampy's `kaiser_best`, librosa 0.9.1's resampler at I_ea/predict.py:79-80) on the 22.05 kHz
+    samples of the reference-held LJ001-0001 pair must give the 16 kHz FILE's samples after its int16 quantisation -- the start of
+    the file bit for bit (an excerpt from sample 0 shares the whole file's time registers), and agrees with the oracle (which the
+    CPU test pins on all three excerpts) to 1e-7 everywhere, ragged batches included."""
+    import json
+    import os
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import audio
+    from tests.common import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "lj001_resample.npz"))
+    x = z["head22"].astype(np.float32) / 32768.0
+    f = audio.design_kaiser_best(22050, 16000, len(x))
+    dev = {k: (torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+    got = ctx.resample_sinc(torch.from_numpy(x)[None].cuda(), dev, f["n_out"]).cpu().numpy()[0]
+    n = int(len(x) * 16000 / 22050)
+    assert np.array_equal(np.floor(got[:n - 80].astype(np.float64) * 32768.0), z["head16"][:n - 80].astype(np.float64))
+    assert got.shape == (f["n_out"],) and not got[n:].any()
+    # against the oracle on other lengths / ratios, and a ragged batch against its clips alone
+    for sr_in, sr_out, n_in in ((22050, 16000, 12347), (16000, 22050, 9000), (44100, 16000, 30000)):
+        xs = _clips(3, n_in, 29)
+        f = audio.design_kaiser_best(sr_in, sr_out, n_in)
+        dev = {k: (torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+        lens = [n_in, n_in - 1234, n_in // 2]
+        got = ctx.resample_sinc(torch.from_numpy(xs).cuda(), dev, f["n_out"], torch.tensor(lens, dtype=torch.int32).cuda()).cpu().numpy()
+        for b, nb in enumerate(lens):
+            ref = R.resample_kaiser_best(xs[b, :nb], sr_in, sr_out)
+            assert np.abs(got[b, :len(ref)] - ref).max() <= 1e-7 * max(1.0, np.abs(ref).max()), (sr_in, sr_out, b)
+            assert not got[b, len(ref):].any()
+
+
+def test_gpu_pcm16_is_the_scripts_truncating_cast(ctx):
+    """B6 on the device (si_pcm16) against the script's own two statements `audio * 32768` + `.astype('int16')`
+    (I_ea/predict.py:204-206) on every value where that cast is defined, 32767 at an exactly saturated +1.0."""
+    g = torch.Generator().manual_seed(3)
+    a = torch.cat([torch.tensor([0.99999, -0.99999, 1.5 / 32768, -1.5 / 32768, 1.0, -1.0, 0.5, -0.25, 0.0, -0.0]),
+                   torch.tanh(3.0 * torch.randn(100003, generator=g))])
+    got = ctx.pcm16(a.cuda().contiguous()).cpu().numpy()
+    with np.errstate(invalid="ignore"):
+        ref = (a * 32768).numpy().astype("int16")
+    ok = (a * 32768).numpy() < 32768.0
+    assert np.array_equal(got[ok], ref[ok]) and (got[~ok] == 32767).all() and int((~ok).sum()) >= 1
+    from speech_inpainting_amd import audio
+    assert np.array_equal(got, audio.to_int16_pcm(a))

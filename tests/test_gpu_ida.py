@@ -163,3 +163,68 @@ def test_ida_inpainting_path_matches_oracle(name, B, N, L, K):
     assert worst_f <= 1e-4 and differing <= max(1, n_units // 500) and worst_w <= 1e-4
     a, nc, nci, nf = R.ida_match_lengths(N, T, f0.shape[-1])
     assert out["audio_gen"].shape == (B, nc * 320) and out["audio_inp"].shape == (B, nci * 320)
+
+
+def test_ida_path_in_the_timed_arithmetic_units_are_near_ties_and_waveforms_meet_the_gate():
+    """The arithmetic `bench.py` TIMES for configs[3] (`configs3_ida`: bf16 encoder + fp16 unit vocoder, the 16 -> 32-channel padded
+    last stage) against the fp32 oracle, at configs[3]'s per-GPU shape (HuBERT-large, layer 18, 16 clips x 4 s, 400 ms mask, K = 100).
+    The k-means arg-min over 1024-dim features is a discrete decision (like A12): (1) unit agreement >= the measured floor;
+    (2) every unit that differs is a near-tie of the ORACLE's own distances -- for x' = x + e the winner g of x' and the winner w of x
+    satisfy d(x, c_g) - d(x, c_w) <= 2 |e| |c_g - c_w| exactly (expand |x + e - c|^2), with e this run's measured feature error;
+    (3) both waveforms within 1e-3 RMS of the oracle's CodeGenerator (front + F0 VQ-VAE + unit HiFi-GAN, fp32) on THIS run's units."""
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd.arch import HubertArch
+    from speech_inpainting_amd.engine import CodeGenerator, F0Quantizer, InpaintingEngine
+    harch = HubertArch.large()
+    B, N, L, K = 16, 64000, 18, 100
+    varch, hsd, gsd, f0sd, emb_c, emb_p, spk, wave, f0 = _ida_setup(harch, B, N, 77, K)
+    frame_start, mask_size = 24000, 6400
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        f_ref0 = R.hubert_get_feats(hsd, harch, wave[0].numpy().astype(np.float64), L)
+    g = torch.Generator().manual_seed(5)
+    rows = torch.randint(0, f_ref0.shape[0], (K,), generator=g)
+    cent = f_ref0[rows] + 0.25 * f_ref0.std() * torch.randn(K, f_ref0.shape[1], generator=g)
+    eng = InpaintingEngine(harch, varch, K, "cuda:0", "bf16", "fp16").load_state(hsd, gsd)
+    gen = CodeGenerator(eng, emb_c, emb_p, f0_quantizer=F0Quantizer(eng, f0sd))
+    out = eng.ida_inpaint_batch(wave.cuda(), frame_start, mask_size, cent, gen, f0, spk, output_layer=L)
+    torch.cuda.synchronize()
+    T = harch.num_frames(N)
+    units_run = torch.cat([eng.ctx.kmeans_assign(out["feats"].reshape(-1, harch.hidden_size), cent.cuda().contiguous()).reshape(2 * B, T).cpu()])
+    n_units = n_diff = 0
+    worst_rel = worst_w = 0.0
+    sample = (0, 5, 11, 15)                                          # the oracle's encoder costs ~2 s per clip and stream
+    for b in sample:
+        y = wave[b].numpy().astype(np.float64)
+        with torch.no_grad():
+            refs = (R.hubert_get_feats(hsd, harch, y, L), R.hubert_get_feats(hsd, harch, R.ida_corrupt(y, frame_start, mask_size), L))
+        for i, x in ((b, refs[0]), (B + b, refs[1])):
+            xr = out["feats"][i].cpu()
+            worst_rel = max(worst_rel, rms(xr, x) / rms(x))
+            want = R.kmeans_assign(x, cent)
+            got = units_run[i]
+            d = ((x[:, None, :] - cent[None]) ** 2).sum(-1)
+            e = (xr - x).norm(dim=1)
+            for t in (want != got).nonzero().reshape(-1).tolist():
+                margin = float(d[t, got[t]] - d[t, want[t]])
+                bound = 2.0 * float(e[t]) * float((cent[got[t]] - cent[want[t]]).norm())
+                assert -1e-3 <= margin <= bound * (1 + 1e-4) + 1e-3, (b, i, t, margin, bound)
+            n_units += want.numel()
+            n_diff += int((want != got).sum())
+        # (3) the waveforms against the oracle's generator on THIS run's units
+        with torch.no_grad():
+            _, nc, nci, nf = R.ida_match_lengths(N, T, f0.shape[-1])
+            z_p = R.f0_vq_codes(R.f0_encoder_forward(f0sd, f0[b][None, :, :nf].float()), f0sd["vq.level_blocks.0.k"])
+            for key, code in (("audio_gen", out["code"][b].cpu()), ("audio_inp", out["code_inpainting"][b].cpu())):
+                ref = R.generator_forward(gsd, varch, R.code_generator_front(code[None], emb_c, z_p, emb_p, spk[b][None]))[0, 0]
+                assert out[key][b].shape == ref.shape
+                worst_w = max(worst_w, rms(out[key][b].cpu(), ref))
+    agree = 1.0 - n_diff / n_units
+    print(f"I_da in bf16 / fp16: feature error {worst_rel:.3e} relative, unit agreement {agree:.4f} ({n_diff} of {n_units} differ, all near-ties within "
+          f"2 |e| |c_g - c_w|), waveforms vs the oracle's generator on this run's units {worst_w:.3e} RMS (signal {rms(out['audio_inp'].cpu()):.3f})")
+    assert worst_rel <= 3e-2 and agree >= 0.95 and worst_w <= 1e-3 and worst_w <= 5e-3 * rms(out['audio_inp'].cpu())
+    # the run's own splice: inside the mask the corrupted stream's units, outside the clean stream's
+    lo, hi = frame_start // 320, (frame_start + mask_size) // 320
+    nc = out["code"].shape[1]
+    assert torch.equal(out["code_inpainting"][:, :lo].cpu(), units_run[:B, :lo]) and torch.equal(out["code_inpainting"][:, lo:hi].cpu(), units_run[B:, lo:hi])
+    assert torch.equal(out["code"].cpu(), units_run[:B, :nc])

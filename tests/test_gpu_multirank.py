@@ -25,8 +25,9 @@ def _free_port():
 def _launch(nproc, script_args, timeout=900):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port())] + script_args
+    # --standalone: torchrun binds its own rendezvous port (no bind / close / reuse race between back-to-back launches)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={nproc}"] + script_args
     return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
 
 
@@ -82,6 +83,11 @@ def test_bench_two_rank_rehearsal_prints_the_contract_line():
     r = json.loads(line)
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 8 and r["scaling"] == "weak"
     assert r["value"] > 0 and r["steps"] == 2 and "roofline" in r
+    # BASELINE's metric names the PER-GPU figure: `value` is the whole-job aggregate the driver's contract asks for,
+    # `value_per_gpu` = the clips of the slowest rank x 4 s / wall -- with equal shards exactly value / n_gpus
+    assert "per GPU" in r["metric"] and r["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    assert r["value_per_gpu"] > 0 and abs(r["value_per_gpu"] * 2 - r["value"]) <= 0.02 * r["value"]
+    assert "whole-job" in r["unit"] and "configs4" not in r            # the single-GPU config legs do not run at N > 1
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "rehearsal_2rank.json"), "w") as f:
         f.write(line + "\n")

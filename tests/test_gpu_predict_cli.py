@@ -55,8 +55,11 @@ km_model: {{n_clusters: 100, LJSpeech: {{path2centroids: '{tmp_path}/kmeans/', k
 
     # same glue, oracle in place of the engine (mel front-end included): int16 samples differ by a couple of LSB at
     # most (the HIP mel is within ~1e-5 of torch's FFT-based one; 1 LSB = 3e-5)
-    w16 = audio.load_audio(str(tmp_path / "wavs" / "clip.wav"), 16000)
-    w22r = audio.load_audio(str(tmp_path / "wavs" / "clip.wav"), 22050)
+    # `librosa.load(path, sr=16000)` / `sr=22050` (I_ea/predict.py:79-80): the oracle's restatement of librosa 0.9.1's resampler
+    raw, sr_file = audio.read_wav(str(tmp_path / "wavs" / "clip.wav"))
+    assert sr_file == 22050
+    w16 = R.resample_kaiser_best(raw, 22050, 16000).astype(np.float32)
+    w22r = raw
     from speech_inpainting_amd.config import load_predict_config
     cfg = load_predict_config(str(tmp_path / "predict.yaml"))
     pos, lm = cfg.mask_pos, cfg.mask_frames

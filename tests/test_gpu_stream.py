@@ -1,0 +1,50 @@
+"""the request front (speech_inpainting_amd/stream.py) -- host clips at the file's rate in, int16 PCM out,
+transfers overlapped with compute -- must return exactly what the un-pipelined calls return."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(enc="fp32", voc="fp32"):
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import InpaintingEngine
+    harch, varch = HubertArch.tiny(), VocoderArch.tiny()
+    return InpaintingEngine(harch, varch, 50, "cuda:0", enc, voc).load_state(synth.synth_hubert_state(harch), synth.synth_generator_state(varch),
+                                                                             synth.synth_codebook(50))
+
+
+@pytest.mark.parametrize("enc,voc", [("fp32", "fp32"), ("bf16", "fp16")])
+def test_stream_front_equals_the_unpipelined_path(enc, voc):
+    """Five requests (uniform and ragged batches, masked and blind, different sizes: both slots are reused with other shapes)
+    through predict_stream against, per request, engine.resample -> predict_clips / predict_clips_ragged -> audio.to_int16_pcm."""
+    from speech_inpainting_amd import audio, synth
+    from speech_inpainting_amd.predict import predict_clips, predict_clips_ragged
+    from speech_inpainting_amd.stream import Request, predict_stream
+    eng = _engine(enc, voc)
+    reqs = []
+    for r, (secs, blind) in enumerate([([1.2, 1.2, 1.2], False), ([1.0, 2.3, 1.6, 0.9], False), ([1.5, 1.5], True), ([2.0, 1.1, 1.7], True), ([0.8] * 5, False)]):
+        clips = [synth.synth_wave(1, int(s * 22050), 300 + 10 * r + i, sr=22050)[0].numpy() for i, s in enumerate(secs)]
+        reqs.append(Request(clips, [8 + 3 * i for i in range(len(secs))], 5, blind, tag=r))
+    got = list(predict_stream(eng, reqs, sr_in=22050, depth=2))
+    assert [g.tag for g in got] == [0, 1, 2, 3, 4]
+    for rq, g in zip(reqs, got):
+        lens = [len(c) for c in rq.clips]
+        raw = torch.zeros(len(lens), max(lens))
+        for i, c in enumerate(rq.clips):
+            raw[i, :lens[i]] = torch.from_numpy(c)
+        ragged = min(lens) != max(lens)
+        w16 = eng.resample(raw.cuda(), 22050, 16000, lens=lens if ragged else None).cpu().numpy()
+        n16 = [int(np.ceil(n * 16000 / 22050)) for n in lens]
+        a16 = [w16[i, :n16[i]] for i in range(len(lens))]
+        if ragged:
+            ref = predict_clips_ragged(eng, a16, list(rq.clips), rq.mask_pos, rq.mask_frames, blind=rq.blind)
+            waves = [ref["wave"][i, :ref["wave_len"][i]] for i in range(len(lens))]
+        else:
+            ref = predict_clips(eng, a16, list(rq.clips), rq.mask_pos, rq.mask_frames, blind=rq.blind)
+            waves = [ref["wave"][i] for i in range(len(lens))]
+        assert torch.equal(g.labels, ref["labels"].cpu()), rq.tag
+        for i in range(len(lens)):
+            assert g.pcm[i].dtype == np.int16 and np.array_equal(g.pcm[i], audio.to_int16_pcm(waves[i])), (rq.tag, i)

@@ -1,11 +1,13 @@
 """Pin the CPU oracle (oracle/ref_cpu.py) to outputs of the reference's own modules
 (tests/golden/*.npz, written by tools/make_goldens.py in the authoring container)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import ref_cpu as R
-from tests.common import load_case, rms
+from tests.common import GOLDEN, load_case, rms
 
 torch.set_num_threads(8)
 
@@ -272,3 +274,31 @@ def test_slaney_filterbank_matches_transformers_librosa_compatible_one():
         d = np.abs(theirs.T - ours).max()
         print(f"sr={sr} n_fft={n_fft} n_mels={n_mels}: max |ours - transformers| = {d:.3e} (filter peak {ours.max():.3e})")
         assert d <= 1e-7 * max(ours.max(), 1e-3) + 1e-9
+
+
+def test_resampler_restatement_reproduces_the_reference_held_16k_file():
+    """f-3: `librosa.load(path, sr=16000)` (I_ea/predict.py:79-80) = resampy's `kaiser_best` in the pinned librosa 0.9.1.  The
+    reference holds ONE fixture for it: I_ea/hifi_gan/test_files/LJ001-0001_22k.wav and _16k.wav are the same utterance at both
+    rates.  tests/golden/lj001_resample.npz (tools/make_resample_fixture.py) carries three excerpts of the two files' int16
+    samples: the oracle's restatement, given the 22.05 kHz samples, must reproduce the 16 kHz samples BIT FOR BIT after the file's
+    int16 quantisation (floor(32768 y)) -- the start of the file (left wing cut at sample 0), 1.8 s of its interior (with the
+    whole-file time registers), and its end (right wing cut at the last sample, zeros behind)."""
+    import json
+    z = np.load(os.path.join(GOLDEN, "lj001_resample.npz"))
+    meta = json.loads(str(z["meta"]))
+    M = 80                                                        # 64 zero crossings / scale = 89 input = 65 output samples of missing neighbours
+    total = 0
+    for name, fo, fi, lo, hi in (("head", 0, 0, 0, M), ("seg", meta["start16"], meta["start22"], M, M), ("tail", meta["tail_start16"], meta["tail_start22"], M, 0)):
+        x22, want = z[name + "22"], z[name + "16"]
+        y = R.resample_kaiser_best(x22.astype(np.float32) / 32768.0, 22050, 16000, fix_length=False, first_output=fo, first_input=fi)
+        n = min(len(y), len(want))
+        q = np.floor(y[:n] * 32768.0)
+        assert np.array_equal(q[lo:n - hi], want[lo:n - hi].astype(np.float64)), name
+        total += n - hi - lo
+        if name == "tail":                                        # resampy stops at int(n * ratio); the file holds zeros from there
+            assert len(y) == meta["n_resampled"] - fo and not want[len(y):].any() and meta["zeros_after"]
+    assert total > 34000
+    # librosa's fix_length: one zero appended up to ceil(n * ratio)
+    x = z["head22"].astype(np.float32) / 32768.0
+    full = R.resample_kaiser_best(x, 22050, 16000)
+    assert len(full) == int(np.ceil(len(x) * 16000 / 22050)) and len(full) - int(len(x) * 16000 / 22050) in (0, 1)

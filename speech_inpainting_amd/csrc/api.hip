@@ -96,6 +96,8 @@ struct si_ctx {
     size_t vl_pin_ints[VL_SLOTS] = {0, 0, 0, 0};
     hipEvent_t vl_ev[VL_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     int vl_next = 0;
+    float* km_cnorm = nullptr;               // |c_k|^2 scratch of si_kmeans_assign (K floats; library-owned, stream-ordered reuse)
+    int km_cnorm_cap = 0;
 };
 
 static char g_create_err[512] = "";
@@ -690,6 +692,7 @@ void si_destroy(si_ctx* ctx) {
     if (!ctx) return;
     if (ctx->wdev) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->wdev); }
     if (ctx->fe_dev) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->fe_dev); }
+    if (ctx->km_cnorm) { (void)hipSetDevice(ctx->device); (void)hipFree(ctx->km_cnorm); }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < si_ctx::VL_SLOTS; ++i) {
         if (ctx->vl_ev[i]) { (void)hipEventSynchronize(ctx->vl_ev[i]); (void)hipEventDestroy(ctx->vl_ev[i]); }
@@ -1091,7 +1094,15 @@ int si_kmeans_assign(si_ctx* ctx, const float* feats, int64_t rows, int D, const
     if (!ctx) return SI_EINVAL;
     if (!feats || !centroids || !labels || rows < 0) return si_fail(ctx, SI_EINVAL, "si_kmeans_assign: NULL / bad argument");
     SI_HIP_CHECK(hipSetDevice(ctx->device));
-    return si_launch_kmeans_assign(ctx, feats, (long)rows, D, centroids, K, labels, sq_dist, static_cast<hipStream_t>(stream));
+    if (K > ctx->km_cnorm_cap) {                                       // (a context is single-threaded and its calls stream-ordered by contract)
+        if (ctx->km_cnorm) { SI_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream))); SI_HIP_CHECK(hipFree(ctx->km_cnorm)); ctx->km_cnorm = nullptr; ctx->km_cnorm_cap = 0; }
+        const int cap = std::max(K, 1024);
+        SI_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ctx->km_cnorm), (size_t)cap * sizeof(float)));
+        ctx->km_cnorm_cap = cap;
+    }
+    const bool mfma = !(getenv("SI_KMEANS_MFMA") && atoi(getenv("SI_KMEANS_MFMA")) == 0);   // (read per call: the test compares both kernels)
+    return si_launch_kmeans_assign(ctx, feats, (long)rows, D, centroids, K, labels, sq_dist, static_cast<hipStream_t>(stream),
+                                   mfma ? ctx->km_cnorm : nullptr);
 }
 
 int si_mel_metrics(si_ctx* ctx, const float* mel_a, const float* mel_b, int B, int D, int L, const float* center, float* out3,
@@ -1161,6 +1172,24 @@ int si_f0_encoder_forward(si_ctx* ctx, const si_f0enc_desc* d, const float* weig
     SI_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const F0Shape ds = f0_down_shape(d->stride_t);
+    {
+        // one persistent launch with the track's activations in LDS (bit-identical to the layer-by-layer form below, which
+        // remains for tracks too long for LDS); SI_F0_FUSED=0 forces the latter (the test compares the two)
+        const bool fused_on = !(getenv("SI_F0_FUSED") && atoi(getenv("SI_F0_FUSED")) == 0);   // (read per call: the test flips it in-process)
+        if (fused_on) {
+            double macs = 0;
+            int Tc = T, cin = d->in_width;
+            for (int i = 0; i < d->down_t; ++i) {
+                const int To = (Tc + 2 * ds.pad - ds.k) / d->stride_t + 1;
+                macs += (double)B * To * d->width * (double)cin * ds.k + (double)d->depth * B * To * ((double)d->n_state * d->width * 3 + (double)d->width * d->n_state);
+                Tc = To; cin = d->width;
+            }
+            macs += (double)B * Tc * d->out_width * (double)d->width * 3;
+            const int frc = si_launch_f0enc_fused(ctx, weights, f0, B, T, h_out, d->in_width, d->out_width, d->width, d->n_state, d->depth, d->down_t,
+                                                  d->stride_t, d->dilation_growth, ds.k, ds.pad, macs, st);
+            if (frc <= 0) return frc;
+        }
+    }
     const size_t slot = need / 3 / sizeof(float);
     float* buf[3] = {static_cast<float*>(workspace), static_cast<float*>(workspace) + slot, static_cast<float*>(workspace) + 2 * slot};
     const float* w = weights;

@@ -224,8 +224,9 @@ int si_launch_codebook_gather(si_ctx* ctx, const int64_t* labels, int B, int D, 
                               const float* cb_raw, int K, float* mel, int Tm, hipStream_t st);
 
 // k-means unit assignment: labels[row] = argmin_k ||x_row - c_k||^2 (first minimum); dist (optional) = that squared distance
+// cnorm_scratch (K floats, device) or null: with it (and D % 32 == 0) the distance GEMM runs on the matrix pipe (exact-fp32 MFMA)
 int si_launch_kmeans_assign(si_ctx* ctx, const float* x, long rows, int D, const float* cent, int K, int64_t* labels, float* dist,
-                            hipStream_t st);
+                            hipStream_t st, float* cnorm_scratch = nullptr);
 
 // loss half of LossFunction.cos_sim + cos_sim_target_labels (f-4): per-frame terms 1 - cos(v, c_target), their
 // fixed-order sum, arg-max labels and cos(c_pred, c_target)
@@ -356,6 +357,9 @@ int si_launch_extend_mel(si_ctx* ctx, const float* mel, int B, int D, int Tm, in
 // I_da CodeGenerator front (f-2): embedding look-ups + frame repeat + channel concat -> (B, nparts * E, F) channels-first
 int si_launch_small_conv1d(si_ctx* ctx, const float* x, const float* w, const float* bias, const float* res, float* y, int B, int Cin,
                            int Tin, int Cout, int Tout, int K, int stride, int dil, int pad, int relu_in, int channels_last, hipStream_t st);
+// the whole F0 encoder in one launch, activations in LDS (vocoder_kernels.hip); 1 = does not fit, launch layer by layer
+int si_launch_f0enc_fused(si_ctx* ctx, const float* weights, const float* f0, int B, int T, float* h_out, int in_width, int out_width, int width,
+                          int n_state, int depth, int down_t, int stride_t, int growth, int dk, int dpad, double macs, hipStream_t st);
 int si_launch_unit_frontend(si_ctx* ctx, const int64_t* code, int Fc, const int64_t* f0_code, int Fp, const float* spk_emb,
                             const float* emb_c, int Kc, const float* emb_p, int Kp, int E, int B, float* out, hipStream_t st);
 // leaky_relu(0.01) -> Conv1d(C -> 1, k, pad k/2) -> tanh ; x (B, L, C) channels-last -> wav (B, L)

@@ -1171,10 +1171,109 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(const float* __restr
     }
 }
 
+// The same assignment as a GEMM on the matrix pipe (exact-fp32 products: v_mfma_f32_32x32x2_f32) with the arg-min in its
+// epilogue: rows x K x D = 6368 x 100 x 1024 per I_da call is 1.3 GFLOP, which the one-workgroup-per-row kernel above ran at
+// 8 TFLOP/s (164 us: every row re-reads the whole centroid table through scalar-ish fp32 FMAs).  One workgroup = 32 rows x a block
+// of up to 128 centroids; its four waves split the D reduction four ways (so that all four SIMDs of the CU work on the 199 row tiles of
+// a call) and meet in LDS; then s_k = |c_k|^2 - 2 x.c_k and the first minimum, as above.  The dot products are exact-fp32
+// products summed in another order than the scalar kernel's, so a label can differ from it only at a near-tie of the distances
+// (the tests hold both kernels to the same near-tie rule against the oracle).  cnorm (K) = |c_k|^2 comes from a small kernel.
+__global__ __launch_bounds__(256) void kmeans_cnorm_kernel(const float* __restrict__ cent, int D, float* __restrict__ cnorm) {
+    const int k = blockIdx.x;
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) { const float v = cent[(long)k * D + d]; s = fmaf(v, v, s); }
+    s = wave_sum(s);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) cnorm[k] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void kmeans_mfma_kernel(const float* __restrict__ x, long rows, int D, const float* __restrict__ cent, int K,
+                                                          const float* __restrict__ cnorm, int64_t* __restrict__ labels, float* __restrict__ dist) {
+    extern __shared__ __attribute__((aligned(16))) char km_smem[];     // 66 KB: above the 64 KB a kernel gets without asking
+    float (*dots)[32][132] = reinterpret_cast<float (*)[32][132]>(km_smem);   // per wave: partial x.c of 32 rows x 128 centroids (+4: bank spread)
+    float (*xxs)[32] = reinterpret_cast<float (*)[32]>(km_smem + 4 * 32 * 132 * sizeof(float));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const long row0 = (long)blockIdx.x * 32;
+    const int Dw = D / 4;                                               // this wave's share of the reduction
+    const long xrow = min(row0 + l31, rows - 1);                        // clamped: rows past the end are computed and dropped
+    const float* xp = x + xrow * D + wave * Dw + half * (Dw / 2);
+    float best = INFINITY;
+    int besti = 0x7fffffff;
+    float xx_row = 0.f;
+    for (int kb = 0; kb < K; kb += 128) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        const float* cp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cp[j] = cent + (long)min(kb + 32 * j + l31, K - 1) * D + wave * Dw + half * (Dw / 2);
+        float xx = 0.f;
+        for (int s4 = 0; s4 < Dw / 8; ++s4) {                           // lane-half h walks floats [h Dw/2, (h+1) Dw/2) of the wave's range
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xp + 4 * s4);
+            f32x4 b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4*>(cp[j] + 4 * s4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xx = fmaf(a[e], a[e], xx);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[j][e], acc[j], 0, 0, 0);
+            }
+        }
+        // D[row][col]: this MFMA's A operand is the x row (M = rows), B the centroid (N = centroids): lane holds col = l31 of tile j,
+        // rows (r & 3) + 8 (r >> 2) + 4 half
+        __syncthreads();                                                // (a previous block's epilogue is done with `dots`)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dots[wave][(r & 3) + 8 * (r >> 2) + 4 * half][32 * j + l31] = acc[j][r];
+        xx += __shfl_xor(xx, 32, 64);
+        if (kb == 0 && half == 0) xxs[wave][l31] = xx;
+        __syncthreads();
+        // arg-min: 8 threads per row, each walks 16 of the block's 128 centroids in ascending order
+        const int r = tid >> 3, c0 = tid & 7;
+        if (kb == 0) xx_row = (xxs[0][r] + xxs[1][r]) + (xxs[2][r] + xxs[3][r]);
+        for (int c = c0; c < 128; c += 8) {
+            const int k = kb + c;
+            if (k < K) {
+                const float dot = (dots[0][r][c] + dots[1][r][c]) + (dots[2][r][c] + dots[3][r][c]);
+                const float sv = cnorm[k] - 2.f * dot;
+                if (sv < best) { best = sv; besti = k; }                // ascending k per thread: first minimum wins
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {                                   // the 8 threads of a row are 8 consecutive lanes
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    const long row = row0 + (tid >> 3);
+    if ((tid & 7) == 0 && row < rows) {
+        labels[row] = besti;
+        if (dist) dist[row] = best + xx_row;
+    }
+}
+
 int si_launch_kmeans_assign(si_ctx* ctx, const float* x, long rows, int D, const float* cent, int K, int64_t* labels, float* dist,
-                            hipStream_t st) {
+                            hipStream_t st, float* cnorm_scratch) {
     if (D <= 0 || D > 8192 || K <= 0) return si_fail(ctx, SI_EINVAL, "kmeans_assign: D=%d (<= 8192) K=%d", D, K);
     if (rows <= 0) return SI_OK;
+    if (cnorm_scratch && D % 32 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 && (reinterpret_cast<size_t>(cent) & 15) == 0) {
+        const size_t km_lds = (4 * 32 * 132 + 4 * 32) * sizeof(float);
+        if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kmeans_mfma_kernel), km_lds)) return rc;
+        si_prof_begin(ctx, "kmeans_assign", 2.0 * rows * (double)K * D, 4.0 * rows * D, st);
+        hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3(K), dim3(256), 0, st, cent, D, cnorm_scratch);
+        hipLaunchKernelGGL(kmeans_mfma_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), km_lds, st, x, rows, D, cent, K, cnorm_scratch, labels, dist);
+        si_prof_end(ctx, st);
+        SI_HIP_CHECK(hipGetLastError());
+        return SI_OK;
+    }
     si_prof_begin(ctx, "kmeans_assign", 2.0 * rows * (double)K * D, 4.0 * rows * D, st);
     hipLaunchKernelGGL(kmeans_assign_kernel, dim3((unsigned)rows), dim3(256), (size_t)D * sizeof(float), st, x, D, cent, K, labels, dist);
     si_prof_end(ctx, st);

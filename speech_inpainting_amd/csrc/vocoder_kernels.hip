@@ -292,3 +292,132 @@ int si_launch_small_conv1d(si_ctx* ctx, const float* x, const float* w, const fl
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;
 }
+
+
+// The whole F0 encoder as ONE launch (row f-2; I_da/src/modules/jukebox.py:11-116, resnet.py:29-97): one workgroup per F0 track keeps
+// every activation of that track in LDS (width 32: 800 -> 400 -> ... -> 50 frames: two buffers of at most T / 2 x 32 floats = 51 KB --
+// a res block's 1 x 1 convolution writes x + conv(relu(t)) IN PLACE over x: each output reads only its own x) and walks the 37
+// convolutions with workgroup barriers between them.  As 37 launches of a one-thread-per-output kernel the encoder took 0.78 ms per
+// call for 0.4 GFLOP (21 us per launch, all of it latency).  Per layer the weights are staged into LDS transposed to [ci][tap][co], so
+// that a thread that owns 8 output channels of one frame reads them as two 16-byte broadcasts per input value: 3 LDS reads per 8 FMAs.
+// Every output is the same fmaf chain as small_conv1d_kernel's (bias first, then ci outer / tap inner, padding taps skipped):
+// bit-identical results.
+struct F0EncParams {
+    const float* weights; const float* f0; float* h_out;
+    int in_width, out_width, width, n_state, depth, down_t, stride_t, growth, T;
+    int dk, dpad;                     // kernel / padding of the strided convolutions
+    int slot;                         // floats per LDS activation buffer
+    int wmax;                         // floats of the largest layer's weights + bias
+};
+
+// global w[co][ci][k], bias[co] -> LDS wl[ci][k][co], bl[co]
+__device__ __forceinline__ void f0_stage_w(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ wl, float* __restrict__ bl,
+                                           int Cout, int Cin, int K) {
+    const int n = Cout * Cin * K;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int co = i / (Cin * K), r = i - co * (Cin * K);           // r = ci * K + k
+        wl[r * Cout + co] = w[i];
+    }
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) bl[i] = bias[i];
+}
+
+// one convolution out of LDS weights: a thread owns 8 consecutive output channels of one output frame.  x: [ci][x_ct] (LDS, or
+// global for the first layer); y: LDS [co][Tout] (may alias res when K == 1), or global channels-last when to_global_cl.
+__device__ __forceinline__ void f0_conv8(const float* __restrict__ x, int x_ct, const float* __restrict__ wl, const float* __restrict__ bl,
+                                         const float* res, float* y, int Cin, int Tin, int Cout, int Tout, int K, int stride, int dil, int pad,
+                                         bool relu_in, bool to_global_cl) {
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const int items = (Cout / 8) * Tout;
+    for (int item = threadIdx.x; item < items; item += blockDim.x) {
+        const int t = item % Tout, co0 = (item / Tout) * 8;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = bl[co0 + c];
+        // (a tap in the padding contributes fmaf(w, 0, acc) = acc: the same value as skipping it, without a branch around the loads,
+        //  so that the compiler can keep several (ci, tap) steps of LDS reads in flight)
+        const int t_in0 = t * stride - pad;
+#pragma unroll 4
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* xr = x + (long)ci * x_ct;
+            for (int k = 0; k < K; ++k) {
+                const int ti = t_in0 + k * dil;
+                const bool in = ti >= 0 && ti < Tin;
+                float v = xr[in ? ti : 0];
+                if (relu_in) v = fmaxf(v, 0.f);
+                v = in ? v : 0.f;
+                const float* wp = wl + (ci * K + k) * Cout + co0;
+                const f32x4v w0 = *reinterpret_cast<const f32x4v*>(wp), w1 = *reinterpret_cast<const f32x4v*>(wp + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { acc[c] = fmaf(w0[c], v, acc[c]); acc[4 + c] = fmaf(w1[c], v, acc[4 + c]); }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float a = acc[c];
+            if (res) a += res[(long)(co0 + c) * Tout + t];
+            if (to_global_cl) y[(long)t * Cout + co0 + c] = a;           // channels-last rows for the bottleneck's arg-min
+            else y[(long)(co0 + c) * Tout + t] = a;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void f0enc_fused_kernel(const F0EncParams p) {
+    extern __shared__ __attribute__((aligned(16))) char f0_smem[];
+    float* X = reinterpret_cast<float*>(f0_smem);
+    float* Y = X + p.slot;
+    float* wl = Y + p.slot;                                            // [ci][k][co] of the current layer
+    float* bl = wl + p.wmax;
+    const int b = blockIdx.x;
+    const float* w = p.weights;
+    const float* x = p.f0 + (long)b * p.in_width * p.T;               // (in_width, T) in global memory
+    int cin = p.in_width, Tc = p.T;
+    for (int i = 0; i < p.down_t; ++i) {
+        const int To = (Tc + 2 * p.dpad - p.dk) / p.stride_t + 1;
+        const float* cw = w; w += (long)p.width * cin * p.dk;
+        const float* cb = w; w += p.width;
+        f0_stage_w(cw, cb, wl, bl, p.width, cin, p.dk);
+        __syncthreads();
+        f0_conv8(x, Tc, wl, bl, nullptr, Y, cin, Tc, p.width, To, p.dk, p.stride_t, 1, p.dpad, false, false);
+        __syncthreads();
+        { float* t_ = X; X = Y; Y = t_; }                              // X = this block's residual stream, Y = scratch
+        x = X; cin = p.width; Tc = To;
+        int dil = 1;
+        for (int j = 0; j < p.depth; ++j) {
+            const float* w3 = w; w += (long)p.n_state * p.width * 3;
+            const float* b3 = w; w += p.n_state;
+            const float* w1 = w; w += (long)p.width * p.n_state;
+            const float* b1 = w; w += p.width;
+            f0_stage_w(w3, b3, wl, bl, p.n_state, p.width, 3);
+            __syncthreads();
+            f0_conv8(X, Tc, wl, bl, nullptr, Y, p.width, Tc, p.n_state, Tc, 3, 1, dil, dil, true, false);
+            __syncthreads();
+            f0_stage_w(w1, b1, wl, bl, p.width, p.n_state, 1);
+            __syncthreads();
+            f0_conv8(Y, Tc, wl, bl, X, X, p.n_state, Tc, p.width, Tc, 1, 1, 1, 0, true, false);   // in place: x <- x + conv1(relu(t))
+            __syncthreads();
+            dil *= p.growth;
+        }
+    }
+    const float* fw = w; w += (long)p.out_width * p.width * 3;
+    f0_stage_w(fw, w, wl, bl, p.out_width, p.width, 3);
+    __syncthreads();
+    f0_conv8(X, Tc, wl, bl, nullptr, p.h_out + (long)b * Tc * p.out_width, p.width, Tc, p.out_width, Tc, 3, 1, 1, 1, false, true);
+}
+
+// SI_OK when launched, negative on error, 1 when the track does not fit LDS (the caller launches the convolutions one by one)
+int si_launch_f0enc_fused(si_ctx* ctx, const float* weights, const float* f0, int B, int T, float* h_out, int in_width, int out_width, int width,
+                          int n_state, int depth, int down_t, int stride_t, int growth, int dk, int dpad, double macs, hipStream_t st) {
+    const int T1 = (T + 2 * dpad - dk) / stride_t + 1;                 // the longest intermediate
+    const size_t slot = ((size_t)std::max(width, n_state) * std::max(T1, 1) + 3) / 4 * 4;
+    size_t wmax = std::max((size_t)width * std::max(in_width, width) * dk, std::max((size_t)n_state * width * 3, (size_t)out_width * width * 3));
+    wmax = (wmax + 3) / 4 * 4;
+    const size_t lds = (2 * slot + wmax + std::max(std::max(width, n_state), out_width)) * sizeof(float);
+    if (lds > 158 * 1024 || B <= 0 || width % 8 || n_state % 8 || out_width % 8) return 1;
+    if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(f0enc_fused_kernel), lds)) return rc;
+    F0EncParams p{weights, f0, h_out, in_width, out_width, width, n_state, depth, down_t, stride_t, growth, T, dk, dpad, (int)slot, (int)wmax};
+    si_prof_begin(ctx, "f0enc_fused", 2.0 * macs, 4.0 * B * ((double)in_width * T + 0.0), st);
+    hipLaunchKernelGGL(f0enc_fused_kernel, dim3(B), dim3(512), lds, st, p);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}

@@ -133,6 +133,18 @@ class InpaintingEngine:
         ms = torch.cat([zi, fs])
         ml = torch.cat([zi, torch.full((B,), int(mask_size), dtype=torch.int32, device=dev)])
         add = torch.cat([torch.zeros(B, dtype=torch.float64, device=dev), torch.full((B,), 1e-6, dtype=torch.float64, device=dev)])
+        if generator.f0_quantizer is None:
+            raise ValueError("ida_inpaint_batch: the CodeGenerator needs its F0Quantizer (the fixed F0 VQ-VAE, I_da/src/model.py:160-166)")
+        # The F0 VQ-VAE's conv encoder (one workgroup per track: 16 of the chip's 256 CUs for ~0.35 ms) depends on nothing the HuBERT
+        # encoder computes: it runs on a side stream UNDER the encoder and is joined before its bottleneck's arg-min.
+        _, nc, nci, nf = ida_match_lengths(N, self.ctx.num_frames(N), f0.shape[-1], code_hop_size, f0_hop)
+        f0 = f0.to(dev, torch.float32)[..., :nf].contiguous()
+        main = torch.cuda.current_stream(dev)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(dev)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            f0_feats = generator.f0_quantizer.features(f0)
         both = torch.cat([wave16, wave16]).contiguous()
         hid = self.extract_features(both, output_layer, "layer_norm" if normalize else None, ms, ml, add)       # (2B, T, H)
         T, H = hid.shape[1], hid.shape[2]
@@ -141,11 +153,9 @@ class InpaintingEngine:
         first = torch.div(fs, code_hop_size, rounding_mode="floor").to(torch.int32)
         last = torch.div(fs + int(mask_size), code_hop_size, rounding_mode="floor").to(torch.int32)
         code_inp = self.ctx.code_splice(code, units[B:].contiguous(), first, last)
-        _, nc, nci, nf = ida_match_lengths(N, T, f0.shape[-1], code_hop_size, f0_hop)
-        f0 = f0.to(dev, torch.float32)[..., :nf].contiguous()
-        if generator.f0_quantizer is None:
-            raise ValueError("ida_inpaint_batch: the CodeGenerator needs its F0Quantizer (the fixed F0 VQ-VAE, I_da/src/model.py:160-166)")
-        z_p = generator.f0_quantizer(f0)                                               # the same F0 track conditions both outputs
+        main.wait_stream(self._side)
+        f0_feats.record_stream(main)
+        z_p = generator.f0_quantizer.codes(f0_feats)                                   # the same F0 track conditions both outputs
         code, code_inp = code[:, :nc].contiguous(), code_inp[:, :nci].contiguous()
         if nc == nci:
             wav = generator(code=torch.cat([code, code_inp]), f0_code=torch.cat([z_p, z_p]),
@@ -438,11 +448,14 @@ class F0Quantizer:
         """f0 (B, 1, T) -> (B, T', 128) encoder output, channels-last."""
         return self.engine.ctx.f0_encoder(self.desc, self.weights, f0.to(self.engine.device, torch.float32).contiguous())
 
-    def __call__(self, f0: torch.Tensor) -> torch.Tensor:
-        """f0 (B, 1, T) -> z_p (B, T') int64, the indices `emb_p` is looked up with."""
-        h = self.features(f0)
+    def codes(self, h: torch.Tensor) -> torch.Tensor:
+        """encoder output (B, T', 128) -> z_p (B, T') int64: the bottleneck's nearest-codebook arg-min (vq.py:117-127)."""
         B, Tp, E = h.shape
         return self.engine.ctx.kmeans_assign(h.reshape(B * Tp, E), self.codebook).reshape(B, Tp)
+
+    def __call__(self, f0: torch.Tensor) -> torch.Tensor:
+        """f0 (B, 1, T) -> z_p (B, T') int64, the indices `emb_p` is looked up with."""
+        return self.codes(self.features(f0))
 
 
 def pack_f0_encoder(state: dict, desc) -> torch.Tensor:

@@ -269,7 +269,30 @@ def test_f0_vqvae_front_matches_oracle(B, T):
         eng.ctx.f0_encoder(desc, q.weights, f0[:, :, :8].contiguous().cuda())
 
 
-@pytest.mark.gpu
+def test_f0_encoder_single_launch_equals_the_layer_by_layer_form():
+    """si_f0_encoder_forward as ONE persistent launch (activations in LDS) against its 37-launch form (SI_F0_FUSED=0, also the route
+    of tracks too long for LDS): bit-identical, for the hubert_lut.json shape at 4 s / 10 s tracks and a 30 s track that does not fit."""
+    import os
+    from speech_inpainting_amd import native, synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    ctx = native.NativeContext(native.make_desc(HubertArch.tiny(), VocoderArch.tiny(), 10), torch.device("cuda:0"))
+    desc = native.F0EncDesc()
+    from speech_inpainting_amd.engine import pack_f0_encoder
+    w = pack_f0_encoder(synth.synth_f0_vqvae_state(desc, 20, seed=5), desc).cuda()
+    g = torch.Generator().manual_seed(9)
+    for B, T in ((16, 797), (3, 2000), (2, 6000)):
+        f0 = torch.randn(B, 1, T, generator=g).cuda()
+        a = ctx.f0_encoder(desc, w, f0)
+        os.environ["SI_F0_FUSED"] = "0"
+        try:
+            b = ctx.f0_encoder(desc, w, f0)
+        finally:
+            os.environ.pop("SI_F0_FUSED", None)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (B, T, float((a - b).abs().max()))
+    ctx.close()
+
+
 def test_f0_vqvae_front_matches_reference_goldens():
     """Row f-2 against the REFERENCE: `si_f0_encoder_forward` + `si_kmeans_assign` on the inputs of tests/golden/f0_vqvae.npz
     against the outputs of the reference's own `Encoder` / `Bottleneck` modules (I_da/src/modules/jukebox.py, vq.py; fixture

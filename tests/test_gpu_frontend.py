@@ -177,3 +177,29 @@ def test_gpu_pcm16_is_the_scripts_truncating_cast(ctx):
     assert np.array_equal(got[ok], ref[ok]) and (got[~ok] == 32767).all() and int((~ok).sum()) >= 1
     from speech_inpainting_amd import audio
     assert np.array_equal(got, audio.to_int16_pcm(a))
+
+
+def test_kmeans_mfma_kernel_agrees_with_the_scalar_kernel_up_to_near_ties(ctx):
+    """The k-means assignment on the matrix pipe (exact-fp32 MFMA, the D reduction split over four waves) against the one-row-per-
+    workgroup scalar kernel (SI_KMEANS_MFMA=0) and the float64 distances: identical labels wherever the two best distances differ by
+    more than 1e-4 relative, squared distances within 1e-4; shapes of the I_da call (6368 x 1024, K = 100), the F0 bottleneck
+    (800 x 128, K = 20), K > 128 (two centroid blocks), and a ragged last row tile."""
+    import os
+    g = torch.Generator().manual_seed(41)
+    for rows, D, K in ((6368, 1024, 100), (800, 128, 20), (1001, 256, 300), (33, 64, 7)):
+        cent = torch.randn(K, D, generator=g)
+        x = cent[torch.randint(0, K, (rows,), generator=g)] + 0.7 * torch.randn(rows, D, generator=g)
+        got, dist = ctx.kmeans_assign(x.cuda(), cent.cuda(), with_distance=True)
+        os.environ["SI_KMEANS_MFMA"] = "0"
+        try:
+            old, dist_old = ctx.kmeans_assign(x.cuda(), cent.cuda(), with_distance=True)
+        finally:
+            os.environ.pop("SI_KMEANS_MFMA", None)
+        d_all = torch.cdist(x.double(), cent.double()).pow(2)
+        top2 = d_all.topk(2, dim=1, largest=False).values
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-4 * top2[:, 1]
+        assert clear.float().mean() > 0.98
+        got, old = got.cpu(), old.cpu()
+        assert torch.equal(got[clear], d_all.argmin(1)[clear]) and torch.equal(old[clear], got[clear]), (rows, D, K)
+        assert int(got.min()) >= 0 and int(got.max()) < K
+        assert torch.allclose(dist.cpu().double(), top2[:, 0], rtol=1e-4, atol=1e-3) and torch.allclose(dist_old.cpu().double(), top2[:, 0], rtol=1e-4, atol=1e-3)

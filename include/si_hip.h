@@ -321,6 +321,12 @@ int si_pcm16(si_ctx* ctx, const float* wav, int64_t n, int16_t* out, si_stream_t
 int si_hifigan_forward(si_ctx* ctx, const float* mel, int B, int Tm, int stretch, float* wav_out,
                        void* workspace, size_t workspace_bytes, si_stream_t stream);
 
+/* `extend_mel` alone (I_ea/hifi_gan/inference_modified.py:16-19): mel (B, num_mels, Tm) -> out (B, num_mels, floor(Tm * 441 / 256)),
+ * both channels-first -- the stretch si_hifigan_forward(stretch = 1) applies internally, as a separate step so that a WINDOW of the
+ * stretched frames can be vocoded with stretch = 0 (the script's three generator passes differ only around the mask,
+ * I_ea/predict.py:123-128,196-207: speech_inpainting_amd/engine.py::vocode_window). */
+int si_extend_mel(si_ctx* ctx, const float* mel, int B, int Tm, float* out, si_stream_t stream);
+
 /* Ragged batches: clip b holds mel_len[b] (HOST int32 (B), 1..Tm) frames of its (D, Tm) slab.  The stretch clamps at the clip's
  * own last frame and every convolution's zero padding begins at its own end, so the first si_vocoder_samples(mel_len[b]) samples
  * of row b equal that clip's waveform alone; the rest of the row (rows are si_vocoder_samples(Tm) long) is zero. */

@@ -1257,6 +1257,15 @@ int si_resample_sinc(si_ctx* ctx, const float* x, const int32_t* n_len, int B, i
                                    static_cast<hipStream_t>(stream));
 }
 
+int si_extend_mel(si_ctx* ctx, const float* mel, int B, int Tm, float* out, si_stream_t stream) {
+    if (!ctx) return SI_EINVAL;
+    if (!mel || !out || B <= 0 || Tm <= 0) return si_fail(ctx, SI_EINVAL, "si_extend_mel: NULL / empty argument");
+    const long Tout = voc_tout(Tm, 1);
+    if (Tout < 1) return si_fail(ctx, SI_EINVAL, "mel of %d frames stretches to nothing", Tm);
+    SI_HIP_CHECK(hipSetDevice(ctx->device));
+    return si_launch_extend_mel_cf(ctx, mel, B, ctx->d.num_mels, Tm, (int)Tout, out, static_cast<hipStream_t>(stream));
+}
+
 int si_pcm16(si_ctx* ctx, const float* wav, int64_t n, int16_t* out, si_stream_t stream) {
     if (!ctx) return SI_EINVAL;
     if (!wav || !out || n < 0) return si_fail(ctx, SI_EINVAL, "si_pcm16: NULL / bad argument");

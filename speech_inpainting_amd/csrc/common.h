@@ -354,6 +354,7 @@ int si_launch_respair(si_ctx* ctx, int C, const unsigned short* y16, unsigned sh
 // tm_len / tout_len (B, device) or null: ragged batches -- clip b holds tm_len[b] mel frames (stride Tm) and tout_len[b] output rows (stride Tout)
 int si_launch_extend_mel(si_ctx* ctx, const float* mel, int B, int D, int Tm, int Tout, int stretch, float* out, int ldo,
                          hipStream_t st, const int32_t* tm_len = nullptr, const int32_t* tout_len = nullptr);
+int si_launch_extend_mel_cf(si_ctx* ctx, const float* mel, int B, int D, int Tm, int Tout, float* out, hipStream_t st);   // (B, D, Tm) -> (B, D, Tout), channels-first
 // I_da CodeGenerator front (f-2): embedding look-ups + frame repeat + channel concat -> (B, nparts * E, F) channels-first
 int si_launch_small_conv1d(si_ctx* ctx, const float* x, const float* w, const float* bias, const float* res, float* y, int B, int Cin,
                            int Tin, int Cout, int Tout, int K, int stride, int dil, int pad, int relu_in, int channels_last, hipStream_t st);

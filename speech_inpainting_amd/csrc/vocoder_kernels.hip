@@ -41,6 +41,34 @@ __global__ __launch_bounds__(256) void extend_mel_kernel(const float* __restrict
     out[(long)b * Touts * ldo + i] = v;
 }
 
+// The same stretch as a stand-alone step, channels-first in and out: (B, D, Tm) -> (B, D, Tout) -- the generator's own input layout,
+// so that a WINDOW of the stretched mel can be vocoded (si_hifigan_forward*, stretch = 0).  The arithmetic is the statement above.
+__global__ __launch_bounds__(256) void extend_mel_cf_kernel(const float* __restrict__ mel, int D, int Tm, int Tout, float rscale, float* __restrict__ out) {
+    const int bc = blockIdx.y;                                         // b * D + c
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= Tout) return;
+    const float* row = mel + (long)bc * Tm;
+    float src = fmaf((float)t + 0.5f, rscale, -0.5f);
+    src = src < 0.f ? 0.f : src;
+    int i0 = (int)floorf(src);
+    if (i0 > Tm - 1) i0 = Tm - 1;
+    const int i1 = i0 + 1 < Tm ? i0 + 1 : Tm - 1;
+    float l1 = src - (float)i0;
+    l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+    const float l0 = 1.f - l1;
+    out[(long)bc * Tout + t] = l0 * row[i0] + l1 * row[i1];
+}
+
+int si_launch_extend_mel_cf(si_ctx* ctx, const float* mel, int B, int D, int Tm, int Tout, float* out, hipStream_t st) {
+    if (B <= 0 || Tout <= 0) return SI_OK;
+    const float rscale = (float)(1.0 / (441.0 / 256.0));
+    si_prof_begin(ctx, "extend_mel", 3.0 * B * Tout * D, 4.0 * B * D * ((double)Tm + Tout), st);
+    hipLaunchKernelGGL(extend_mel_cf_kernel, dim3((Tout + 255) / 256, B * D), dim3(256), 0, st, mel, D, Tm, Tout, rscale, out);
+    si_prof_end(ctx, st);
+    SI_HIP_CHECK(hipGetLastError());
+    return SI_OK;
+}
+
 int si_launch_extend_mel(si_ctx* ctx, const float* mel, int B, int D, int Tm, int Tout, int stretch, float* out, int ldo,
                          hipStream_t st, const int32_t* tm_len, const int32_t* tout_len) {
     if (B <= 0 || Tout <= 0) return SI_OK;

@@ -178,6 +178,54 @@ class InpaintingEngine:
     def vocode(self, mel: torch.Tensor, stretch: bool = True) -> torch.Tensor:
         return self.ctx.hifigan_forward(mel, stretch)
 
+    # ---- the script's three generator passes (I_ea/predict.py:123-128,196-207) differ only around the mask
+    def receptive_radius(self) -> int:
+        """Output samples (one side) an input frame of the generator can reach, from the architecture: conv_pre (k 7) 3 frames,
+        per stage the transposed conv (ceil(k / u) + 1 input rows) and the widest ResBlock (sum over its dilations of (k - 1) / 2 *
+        (d + 1) rows for ResBlock1, (k - 1) / 2 * d for ResBlock2), conv_post 3 samples; conservative (whole rows)."""
+        v = self.varch
+        hop = 1
+        for u in v.upsample_rates:
+            hop *= u
+        r, per_row = 3 * hop, hop                                    # conv_pre at the frame rate
+        two = str(v.resblock) == "1"
+        for u, k in zip(v.upsample_rates, v.upsample_kernel_sizes):
+            r += (-(-k // u) + 1) * per_row                           # the transposed conv, in rows of its input
+            per_row //= u
+            r += max(sum((rk - 1) // 2 * (d + (1 if two else 0)) for d in dil) for rk, dil in zip(v.resblock_kernel_sizes, v.resblock_dilation_sizes)) * per_row
+        return r + 3
+
+    def vocode_window(self, wave_base: torch.Tensor, mel_var: torch.Tensor, frame_pos: Sequence[int], lm: int) -> torch.Tensor:
+        """The waveform of `mel_var` (B, 80, Tm), which differs from the mel that produced `wave_base` ONLY in frames
+        [frame_pos[b], frame_pos[b] + lm): the generator runs on a window of the stretched frames around the change (as a ragged
+        batch: a window clamped at a clip edge keeps that edge's real zero padding) and the samples the change can reach are spliced
+        into a copy of `wave_base`.  Every output sample of the generator is the same fixed-order sum wherever its tile falls, so
+        the result is BIT-IDENTICAL to a full pass (asserted per vocoder mode in tests/test_gpu_configs.py)."""
+        import math
+        ext = self.ctx.extend_mel(mel_var.contiguous())
+        B, D, Tout = ext.shape
+        hop = wave_base.shape[1] // Tout
+        R = self.receptive_radius()
+        Rf = -(-R // hop)
+        r = 441.0 / 256.0
+        spans = []
+        for b in range(B):
+            p = int(frame_pos[b])
+            c0 = max(int(math.floor((p - 0.5) * r - 0.5)) - 1, 0)      # stretched frames whose two source frames touch [p, p + lm)
+            c1 = min(int(math.ceil((p + lm + 0.5) * r - 0.5)) + 1, Tout)
+            spans.append((max(c0 - 2 * Rf, 0), min(c1 + 2 * Rf, Tout)))
+        W = max(w1 - w0 for w0, w1 in spans)
+        win = torch.zeros(B, D, W, dtype=torch.float32, device=self.device)
+        for b, (w0, w1) in enumerate(spans):
+            win[b, :, :w1 - w0] = ext[b, :, w0:w1]
+        out = self.vocode_ragged(win, [w1 - w0 for w0, w1 in spans], stretch=False)
+        wave = wave_base.clone()
+        for b, (w0, w1) in enumerate(spans):
+            s0 = w0 * hop + (Rf * hop if w0 > 0 else 0)               # a window edge that is not a clip edge: its first / last Rf frames
+            s1 = w1 * hop - (Rf * hop if w1 < Tout else 0)            # see missing neighbours and are dropped
+            wave[b, s0:s1] = out[b, s0 - w0 * hop:s1 - w0 * hop]
+        return wave
+
     def mel(self, wave22: torch.Tensor, mask_start: Optional[torch.Tensor] = None, mask_end: Optional[torch.Tensor] = None,
             normalize: bool = True) -> torch.Tensor:
         """Vocoder-side front-end (I_ea/predict.py:99-106): zero [mask_start, mask_end) of each raw 22.05 kHz clip,

@@ -25,7 +25,7 @@ EXPORTS = ["si_version", "si_create", "si_destroy", "si_last_error", "si_load_we
            "si_codebook_splice_varlen", "si_hifigan_forward_varlen", "si_mel_frontend_varlen",
            "si_codebook_splice_labels", "si_codebook_metrics", "si_kmeans_assign", "si_mel_metrics", "si_sisdr", "si_unit_frontend",
            "si_f0_encoder_weight_floats", "si_f0_encoder_frames", "si_f0_encoder_workspace_bytes", "si_f0_encoder_forward",
-           "si_resample_poly", "si_resample_sinc", "si_pcm16", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
+           "si_resample_poly", "si_resample_sinc", "si_pcm16", "si_extend_mel", "si_hifigan_forward", "si_mel_frames", "si_mel_workspace_bytes", "si_mel_frontend", "si_num_frames",
            "si_vocoder_samples", "si_profile_start", "si_profile_filter", "si_profile_stop",
            "si_debug_capture", "si_debug_size"]
 
@@ -187,6 +187,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.si_resample_poly.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.si_resample_sinc.argtypes = [vp, vp, vp, i32, i32, C.POINTER(SincFilter), i32, vp, vp]
     lib.si_pcm16.argtypes = [vp, vp, C.c_int64, vp, vp]
+    lib.si_extend_mel.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.si_hifigan_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, sz, vp]
     lib.si_mel_frames.argtypes = [i32]
     lib.si_mel_workspace_bytes.argtypes = [vp, i32, i32, C.POINTER(sz)]
@@ -580,6 +581,17 @@ class NativeContext:
             out = torch.empty(wav.shape, dtype=torch.int16, device=self.device)
         assert out.is_cuda and out.dtype == torch.int16 and out.is_contiguous() and out.numel() == wav.numel()
         self._check(self.lib.si_pcm16(self._h, _ptr(wav), wav.numel(), _ptr(out), self._stream()), "si_pcm16")
+        return out
+
+    def extend_mel(self, mel: torch.Tensor) -> torch.Tensor:
+        """(B, D, Tm) -> (B, D, floor(Tm * 441 / 256)): the x441/256 stretch alone (the generator's input with stretch=False)."""
+        assert mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous() and mel.dim() == 3 and mel.shape[1] == self.desc.num_mels
+        B, D, Tm = mel.shape
+        hop = 1
+        for i in range(self.desc.num_ups):
+            hop *= self.desc.up_rates[i]
+        out = torch.empty(B, D, self.vocoder_samples(Tm, True) // hop, dtype=torch.float32, device=self.device)
+        self._check(self.lib.si_extend_mel(self._h, _ptr(mel), B, Tm, _ptr(out), self._stream()), "si_extend_mel")
         return out
 
     def hifigan_forward(self, mel: torch.Tensor, stretch: bool = True) -> torch.Tensor:

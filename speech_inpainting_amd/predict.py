@@ -96,15 +96,27 @@ def predict_resident(engine: InpaintingEngine, wave: torch.Tensor, wave22: torch
         e22 = torch.tensor([min(max(int(b), 0), n22) for _, b in mask22], dtype=torch.int32, device=dev)
         mel = engine.mel(wave22, s22, e22)                                          # predict.py:99-106 on the GPU
     pos = torch.tensor(list(mask_pos), dtype=torch.int32, device=dev)
-    out = engine.predict_batch(wave, mel, pos, mask_frames, blind=blind)
+    if diagnostics and not blind:
+        # The script's three generator passes (masked / expected / inpainted mel, I_ea/predict.py:123-128,196-207) differ only in the
+        # Lm spliced frames: ONE full pass (the masked mel), the other two over the window the spliced frames can reach
+        # (engine.vocode_window: bit-identical to full passes).
+        feats = engine.encode(wave, (pos * 320 + 80).to(torch.int32), torch.full_like(pos, max(mask_frames * 320 - 81, 0)))
+        mel2 = mel.clone()
+        labels = engine.splice(feats, pos, mask_frames, mel2)
+        base = engine.vocode(mel, stretch=True)
+        out = {"feats": feats, "labels": labels, "mel": mel2, "hifi_masked": base,
+               "wave": engine.vocode_window(base, mel2, list(mask_pos), mask_frames)}
+    else:
+        out = engine.predict_batch(wave, mel, pos, mask_frames, blind=blind)
+        if diagnostics:
+            out["hifi_masked"] = engine.vocode(mel, stretch=True)
     out["mel_masked"] = mel
     if diagnostics:
-        out["hifi_masked"] = engine.vocode(mel, stretch=True)
         if target_labels is not None and not blind:
             tgt = target_labels.to(dev, torch.int64).contiguous()
             exp = mel.clone()
             engine.splice_labels(tgt, pos, exp)
-            out["expected_inpaint"] = engine.vocode(exp, stretch=True)
+            out["expected_inpaint"] = engine.vocode_window(out["hifi_masked"], exp, list(mask_pos), mask_frames)
             m = engine.codebook_metrics(out["feats"], pos, mask_frames, tgt)
             out["loss"], out["cos_pred_target"] = m["loss"], m["cos_pred_target"]
     return out

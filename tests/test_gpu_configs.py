@@ -114,6 +114,40 @@ def test_vocoder_is_shift_consistent():
     assert rms(b[lo + 256:hi + 256].cpu(), a[lo:hi].cpu()) <= 1e-5
 
 
+@pytest.mark.parametrize("voc", ["fp32", "bf16x3", "fp16", "bf16"])
+def test_windowed_generator_passes_are_bit_identical_to_full_passes(voc):
+    """The script runs the generator three times (masked, expected, inpainted mel: I_ea/predict.py:123-128,196-207); the mels differ
+    only in the Lm spliced frames, so `predict_resident(diagnostics=True)` runs ONE full pass and the other two over the window the
+    spliced frames can reach.  Against three full passes: bit-identical, in every vocoder mode, with masks at the start, in the
+    middle and at the end of a clip (windows clamped at a clip edge keep that edge's real zero padding)."""
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.predict import predict_resident
+    harch, varch = HubertArch.tiny(), VocoderArch.v1()
+    eng, _ = _mk(harch, varch, "fp32", voc)
+    B, n16 = 3, 48000
+    n22 = n16 * 441 // 320
+    wave = synth.synth_wave(B, n16, 71).cuda()
+    wave22 = synth.synth_wave(B, n22, 72, sr=22050).cuda()
+    lm = 10
+    pos = [1, 70, harch.num_frames(n16) - lm]
+    tgt = torch.randint(0, 100, (B, lm), generator=torch.Generator().manual_seed(3))
+    out = predict_resident(eng, wave, wave22, pos, lm, diagnostics=True, target_labels=tgt)
+    # three full passes
+    full_inp = eng.vocode(out["mel"], stretch=True)
+    full_masked = eng.vocode(out["mel_masked"], stretch=True)
+    exp = out["mel_masked"].clone()
+    eng.splice_labels(tgt.cuda(), torch.tensor(pos, dtype=torch.int32).cuda(), exp)
+    full_exp = eng.vocode(exp, stretch=True)
+    torch.cuda.synchronize()
+    assert not torch.equal(full_inp, full_masked) and not torch.equal(full_exp, full_masked)
+    assert torch.equal(out["hifi_masked"], full_masked)
+    assert torch.equal(out["wave"], full_inp), float((out["wave"] - full_inp).abs().max())
+    assert torch.equal(out["expected_inpaint"], full_exp), float((out["expected_inpaint"] - full_exp).abs().max())
+    # the window really is a fraction of the clip: Lm frames stretch to ~19, + 4 receptive radii of 16 frames
+    assert eng.receptive_radius() == 3993 and out["wave"].shape[1] // 256 > 3 * (19 + 4 * 16) - 20
+
+
 def test_config5_ragged_lengths_are_bucketed_and_match_per_clip_oracle():
     """configs[4]: variable-length clips (here 1.0 / 1.5 / 1.0 / 2.2 s), blind and masked, through predict_ragged:
     every clip must equal the oracle run on that clip alone (mel front-end included)."""

@@ -237,6 +237,7 @@ class NativeContext:
         must not be used after this call (the holder is dropped here so a stale view cannot be handed out again)."""
         self._wholder = None
         self._ws = None
+        self._ws_mel = self._ws_mel_old = None
         if getattr(self, "_h", None) and self._h.value:
             self.lib.si_destroy(self._h)
             self._h = C.c_void_p(0)
@@ -391,14 +392,10 @@ class NativeContext:
         assert (mask_start is None) == (mask_end is None)
         for m in (mask_start, mask_end):
             assert m is None or (m.is_cuda and m.dtype == torch.int32 and m.numel() == B and m.is_contiguous())
-        need = C.c_size_t(0)
-        self._check(self.lib.si_mel_workspace_bytes(self._h, B, N, C.byref(need)), "si_mel_workspace_bytes")
-        if self._ws is None or self._ws.numel() < need.value:
-            self._ws = None
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        ws = self._mel_workspace(B, N)
         out = torch.empty(B, 80, Tm, dtype=torch.float32, device=self.device)
         self._check(self.lib.si_mel_frontend_varlen(self._h, _ptr(wave22), _ptr(mask_start), _ptr(mask_end), lens.ctypes.data_as(C.c_void_p),
-                                                    int(normalize), B, N, _ptr(out), _ptr(self._ws), self._ws.numel(), self._stream()),
+                                                    int(normalize), B, N, _ptr(out), _ptr(ws), ws.numel(), self._stream()),
                     "si_mel_frontend_varlen")
         return out
 
@@ -605,6 +602,17 @@ class NativeContext:
                                                 self._stream()), "si_hifigan_forward")
         return out
 
+    def _mel_workspace(self, B: int, N: int) -> torch.Tensor:
+        """The mel front-end's OWN scratch (not the encoder / vocoder workspace: the front-end may run on a side stream under the
+        encoder).  Grown only; a buffer that is replaced stays referenced until the next call, so work still queued on it is safe."""
+        need = C.c_size_t(0)
+        self._check(self.lib.si_mel_workspace_bytes(self._h, B, N, C.byref(need)), "si_mel_workspace_bytes")
+        cur = getattr(self, "_ws_mel", None)
+        if cur is None or cur.numel() < need.value:
+            self._ws_mel_old = cur
+            self._ws_mel = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        return self._ws_mel
+
     def mel_frontend(self, wave22: torch.Tensor, mask_start: Optional[torch.Tensor] = None,
                      mask_end: Optional[torch.Tensor] = None, normalize: bool = True) -> torch.Tensor:
         """(B, N22) raw 22.05 kHz clips -> (B, 80, Tm) log-mel; the span [mask_start, mask_end) of each clip is zeroed first."""
@@ -616,14 +624,10 @@ class NativeContext:
         assert (mask_start is None) == (mask_end is None)
         for m in (mask_start, mask_end):
             assert m is None or (m.is_cuda and m.dtype == torch.int32 and m.numel() == B and m.is_contiguous())
-        need = C.c_size_t(0)
-        self._check(self.lib.si_mel_workspace_bytes(self._h, B, N, C.byref(need)), "si_mel_workspace_bytes")
-        if self._ws is None or self._ws.numel() < need.value:
-            self._ws = None
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        ws = self._mel_workspace(B, N)
         out = torch.empty(B, 80, Tm, dtype=torch.float32, device=self.device)
         self._check(self.lib.si_mel_frontend(self._h, _ptr(wave22), _ptr(mask_start), _ptr(mask_end), int(normalize), B, N,
-                                             _ptr(out), _ptr(self._ws), self._ws.numel(), self._stream()), "si_mel_frontend")
+                                             _ptr(out), _ptr(ws), ws.numel(), self._stream()), "si_mel_frontend")
         return out
 
     def capture(self, names, capacity: int = 0):

@@ -48,3 +48,4 @@ def test_stream_front_equals_the_unpipelined_path(enc, voc):
         assert torch.equal(g.labels, ref["labels"].cpu()), rq.tag
         for i in range(len(lens)):
             assert g.pcm[i].dtype == np.int16 and np.array_equal(g.pcm[i], audio.to_int16_pcm(waves[i])), (rq.tag, i)
+

@@ -11,13 +11,18 @@ out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ps /tmp/pf /tmp/pw /tmp/pc
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps -- python3 $root/bench.py --steps 5 --warmup 2 --cpu-clips 0 > $out/${tag}_bench.json 2> $out/${tag}_bench_stderr.txt || exit 1
+# (--no-config-legs: the configs[3] / configs[4] legs launch the same kernel instantiations on other shapes and would dilute the
+#  per-kernel averages that roofline.avg_launch_ms is checked against; they get their own pass below)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps -- python3 $root/bench.py --steps 5 --warmup 2 --cpu-clips 0 --no-config-legs > $out/${tag}_bench.json 2> $out/${tag}_bench_stderr.txt || exit 1
 cp /tmp/ps/*/*_kernel_stats.csv $out/${tag}_kernel_stats.csv
 cp /tmp/ps/*/*_agent_info.csv $out/${tag}_agent_info.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- python3 $root/bench.py --steps 1 --warmup 1 --cpu-clips 0 --no-kernel-events --no-fp32-leg > /tmp/pf.log 2>&1 || exit 1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- python3 $root/bench.py --steps 1 --warmup 1 --cpu-clips 0 --no-kernel-events --no-fp32-leg > /tmp/pw.log 2>&1 || exit 1
+rm -rf /tmp/pl
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pl -- python3 $root/bench.py --only-config-legs --steps 6 > $out/${tag}_legs.json 2> $out/${tag}_legs_stderr.txt || exit 1
+cp /tmp/pl/*/*_kernel_stats.csv $out/${tag}_legs_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- python3 $root/bench.py --steps 1 --warmup 1 --cpu-clips 0 --no-kernel-events --no-fp32-leg --no-config-legs > /tmp/pf.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- python3 $root/bench.py --steps 1 --warmup 1 --cpu-clips 0 --no-kernel-events --no-fp32-leg --no-config-legs > /tmp/pw.log 2>&1 || exit 1
 cd $root/tools && python3 collect_traffic.py /tmp/pf/*/*_counter_collection.csv /tmp/pw/*/*_counter_collection.csv $out/${tag}_hbm_traffic.json
 cd /tmp
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d /tmp/pc -- python3 $root/bench.py --steps 2 --warmup 1 --cpu-clips 0 --no-kernel-events --no-fp32-leg > /tmp/pc.log 2>&1 || exit 1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d /tmp/pc -- python3 $root/bench.py --steps 2 --warmup 1 --cpu-clips 0 --no-kernel-events --no-fp32-leg --no-config-legs > /tmp/pc.log 2>&1 || exit 1
 cd $root/tools && python3 collect_pmc.py /tmp/pc/*/*_counter_collection.csv /tmp/pc/*/*_kernel_trace.csv $out/${tag}_clock_mfma.json > $out/${tag}_clock_mfma.txt
 echo "profiles collected: $out/${tag}_*"

@@ -219,6 +219,8 @@ def timed_leg(eng, step, steps, warmup):
     prof = eng.ctx.profile_stop()
     roof, fams, tot = roofline_of(prof, 2)
     roof["kernel_ms_per_step"] = round(tot / 2, 3)
+    # the committed PMC table (profiles/rNN_hbm_traffic.json) holds bytes per launch of the configs[1] shapes: not this leg's launches
+    roof["traffic"], roof["traffic_source"] = None, "not collected for this leg (the PMC table is per launch of the configs[1] step)"
     return wall, roof, fams, out
 
 

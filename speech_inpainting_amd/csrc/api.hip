@@ -81,6 +81,7 @@ struct si_ctx {
     std::map<const void*, size_t> dyn_lds;   // per kernel: dynamic-LDS limit already raised on this context's device
     // arithmetic-path options, read from the environment when the context is created (all default to 1)
     bool opt_voc_opready = true, opt_voc_res16 = true, opt_enc_opready = true, opt_att_bf16 = true, opt_enc_lingemm = true;
+    bool opt_enc_posconv = true;             // the positional conv on posconv.hip in the bf16 encoder mode (SI_ENC_POSCONV=0: the generic tap-GEMM)
     int opt_gemm256 = 1;                     // encoder GEMMs on 256 x 256 tiles: 0 never, 1 by the shape rule, 2 whenever the shape allows (tests)
     int opt_voc_chain = 1;                   // whole-resblock kernel on the C = 32 stage (SI_VOC_CHAIN=0: one launch per conv pair)
     int opt_voc_fuse = 1;                    // 0: never, 1: every covered width, otherwise a mask of the channel counts to fuse (32 | 64 | 128 | 256)
@@ -682,6 +683,7 @@ int si_create(si_ctx** out, int device_id, const si_model_desc* desc) {
     ctx->opt_enc_opready = env_flag("SI_ENC_OPREADY");
     ctx->opt_att_bf16 = env_flag("SI_ATT_BF16");
     ctx->opt_enc_lingemm = env_flag("SI_ENC_LINGEMM");
+    ctx->opt_enc_posconv = env_flag("SI_ENC_POSCONV");
     ctx->opt_gemm256 = getenv("SI_ENC_GEMM256") ? atoi(getenv("SI_ENC_GEMM256")) : 1;
     plan_layout(ctx);
     *out = ctx;
@@ -970,7 +972,15 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     // as attention keys (modeling_hubert.py:428-437 / 573-582)
     if (vframes && (rc = si_launch_zero_padded_rows(ctx, h, B, T, H, vframes, st))) return rc;
     // A4: h2 = h + gelu(pos_conv(h) + b)
-    {
+    bool pos_done = false;
+    if (d.encoder_math == SI_MATH_BF16 && ctx->opt_enc_posconv && L.pos.has_bias) {
+        // the dedicated kernel (posconv.hip): N = the group's own width, the group's weights once per workgroup
+        const int prc = si_launch_posconv(ctx, h, h2, ctx->wdev + L.pos.w, wf(ctx, L.pos.bias), B, T, T, H, d.pos_conv_groups, d.pos_conv_kernel,
+                                          L.pos.Npad, d.pos_conv_kernel / 2, d_rowoff, vl ? dL(d.num_conv) : nullptr, (double)BT, st);
+        if (prc < 0) return prc;
+        pos_done = prc == 0;
+    }
+    if (!pos_done) {
         TapGemmParams p = gemm_params(ctx, L.pos);
         p.x = h; p.out = h2; p.res = h;
         p.nseg = B; p.Lin = T; p.M = T; p.ldx = H; p.x_seg_stride = (long)T * H;

@@ -201,6 +201,10 @@ int si_launch_attention(si_ctx* ctx, const float* qkv, float* out, int B, int T,
 int si_launch_attention_bf16in(si_ctx* ctx, const unsigned short* qkv16, int B, int T, int H, int heads, hipStream_t st,
                                unsigned short* out16, const int32_t* valid_frames = nullptr, const int32_t* row_off = nullptr,
                                double real_t2 = 0.0);
+// HuBERT's positional conv in the bf16 encoder mode (posconv.hip): out = x + gelu(conv(x) + b) on (rows, H) fp32, the group's weights
+// streamed once per workgroup; returns 1 when the shape is not covered (the caller runs the tap-GEMM)
+int si_launch_posconv(si_ctx* ctx, const float* x, float* out, const void* w, const float* bias, int B, int T, int Tmax, int H, int groups,
+                      int ntaps, int Npad, int pad, const int32_t* row_off, const int32_t* lens, double rows_total, hipStream_t st);
 // ragged batches: (B, Tmax, C) padded rows <-> packed rows [row_off[b], row_off[b + 1]); unpack zeroes the padded rows
 int si_launch_repack_rows(si_ctx* ctx, const float* src, float* dst, int B, int Tmax, int C, const int32_t* row_off, bool unpack, hipStream_t st);
 // valid_frames[b] = conv-stack length of valid_len[b] samples (modeling_hubert.py:664-677), clamped to [1, T]

@@ -155,3 +155,60 @@ def test_bf16_tiled_attention_kernel_at_T499():
     rel = rms(a.cpu(), ref) / rms(ref)
     print(f"bf16 encoder, T = 499 (tiled attention kernel): head output relative rms error {rel:.3e} vs the fp32 oracle")
     assert rel <= 2e-2
+
+
+@pytest.mark.parametrize("H,heads", [(768, 12), (1024, 16)])
+def test_posconv_kernel_against_a_float64_convolution_of_the_same_bf16_operands(H, heads):
+    """The dedicated positional-conv kernel of the bf16 encoder (posconv.hip: 48 / 64 channels per group) and the generic tap-GEMM
+    (SI_ENC_POSCONV=0, read when a context is created), each against a float64 grouped convolution of the SAME bf16-rounded operands
+    (the captured projection output, the folded weights): h + GELU(conv(h) + b) within fp32 accumulation error for both -- on 4 s
+    clips (two clips per workgroup), 10 s clips (512-row blocks), 10.6 s clips (two blocks per clip); then a ragged batch (packed
+    rows), where every clip must still be bit-identical to that clip alone."""
+    import os
+    import torch.nn.functional as F
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import InpaintingEngine
+    # pre-LN ("stable") flavour: the tap `encoder_in` is then the positional conv's output itself, h + gelu(conv(h) + b)
+    harch = HubertArch.tiny(hidden_size=H, num_attention_heads=heads, num_hidden_layers=1, intermediate_size=512,
+                            num_conv_pos_embeddings=128, num_conv_pos_embedding_groups=16, do_stable_layer_norm=True)
+    varch = VocoderArch.tiny()
+    hsd, gsd, cb = synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook(50)
+
+    def make():
+        return InpaintingEngine(harch, varch, 50, "cuda:0", "bf16", "fp16").load_state(hsd, gsd, cb)
+    new = make()
+    os.environ["SI_ENC_POSCONV"] = "0"
+    try:
+        old = make()
+    finally:
+        os.environ.pop("SI_ENC_POSCONV", None)
+    w = R._conv_weight(hsd, "base_model.encoder.pos_conv_embed.conv", dim=2).to(torch.bfloat16).double()
+    bias = hsd["base_model.encoder.pos_conv_embed.conv.bias"].double()
+    torch.set_num_threads(16)
+    for B, N in ((3, 64000), (2, 160000), (1, 170000)):
+        wave = synth.synth_wave(B, N, 13).cuda()
+        T = harch.num_frames(N)
+        res = {}
+        for name, eng in (("posconv", new), ("tapgemm", old)):
+            caps = eng.ctx.capture(["projected", "encoder_in"], capacity=B * T * H)
+            eng.encode(wave)
+            torch.cuda.synchronize()
+            res[name] = {k: v.cpu().reshape(B, T, H) for k, v in caps.items()}
+            eng.ctx.clear_captures()
+        assert torch.equal(res["posconv"]["projected"], res["tapgemm"]["projected"])
+        h = res["posconv"]["projected"]
+        conv = F.conv1d(h.to(torch.bfloat16).double().transpose(1, 2), w, bias, padding=64, groups=16)[:, :, :-1].transpose(1, 2)
+        ref = h.double() + F.gelu(conv)
+        e_new, e_old = rms(res["posconv"]["encoder_in"], ref) / rms(ref), rms(res["tapgemm"]["encoder_in"], ref) / rms(ref)
+        print(f"H={H} B={B} T={T}: h + gelu(posconv(h)) vs float64 on the same bf16 operands: posconv.hip {e_new:.2e}, tap-GEMM {e_old:.2e} relative")
+        d = rms(res["posconv"]["encoder_in"], res["tapgemm"]["encoder_in"]) / rms(ref)
+        print(f"        the two kernels differ by {d:.2e} relative (fp32 sum order)")
+        assert e_new <= 2e-5 and e_old <= 2e-5 and abs(e_new - e_old) <= 1e-6 and d <= 1e-6
+    lens = [64000, 100000, 52345, 160000, 80000]
+    wave = synth.synth_wave(len(lens), max(lens), 14)
+    got = new.encode_ragged(wave.cuda(), lens)
+    for i, n in enumerate(lens):
+        alone = new.encode(wave[i:i + 1, :n].contiguous().cuda())
+        assert torch.equal(got[i, :alone.shape[1]], alone[0]), (H, i)

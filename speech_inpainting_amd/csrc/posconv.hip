@@ -11,7 +11,7 @@
 //     (256 workgroups x 590 KB = 151 MB for 32 x 4 s clips);
 //   * the clips' rows (+ 127 halo rows, zero outside the clip: the conv's padding) are staged ONCE into LDS as bf16 -- every tap is
 //     then a row offset into that tile, and a k-step of 32 flattened (tap, ci) elements is, per lane, one 16-byte read inside one
-//     row (Cg % 8 == 0); rows padded by 16 bytes: conflict-free operand reads (112- / 144-byte rows: enumerated);
+//     row (Cg % 8 == 0); 96- / 160-byte rows: conflict-free operand reads for every first row and tap phase (enumerated);
 //   * weights: chunks of 4 k-steps (128 flattened K x Cg rows) through a double buffer, global -> registers a chunk ahead -> LDS,
 //     one barrier per chunk = 48 / 64 MFMAs per wave; read straight from the tap-GEMM's packed layout W[g][tap][n][ci];
 //   * orientation D^T = W x X^T (lingemm.hip): a lane holds one frame and four consecutive channels: 16-byte residual reads / stores.
@@ -52,10 +52,14 @@ __device__ __forceinline__ float pc_gelu_erf(float x) { return 0.5f * x * (1.0f 
 template <int CG>
 __global__ __launch_bounds__(PC_NT, 1) void posconv_kernel(const PosConvParams p) {
     constexpr int NTC = CG / 16;                                       // MFMA column tiles
-    constexpr int RS = CG * 2 + 16;                                    // bytes per LDS row of the activation tile
+    // bytes per LDS row of the activation tile / per weight row of a chunk: by enumeration over the hardware's ds_read_b128 lane groups
+    // (tools/lds_conflicts.py) 96 (unpadded) and 160 are conflict-free for the operand read at any first row and tap phase, 288 for the
+    // weight rows; the first choice here (+16 bytes: 112 / 144 / 272) was 2-way conflicted everywhere -- PMC: 47 % of the kernel's LDS
+    // cycles were bank conflicts
+    constexpr int RS = CG == 48 ? 96 : 160;
     constexpr int XROWS = PC_HALF_ROWS + 128;                          // rows per half: 256 outputs + 127 halo (+1)
     constexpr int XBYTES = XROWS * RS;
-    constexpr int WROW = PC_KC * 64 + 16;                              // bytes per weight row of a chunk (4 k-steps x 64 B + pad)
+    constexpr int WROW = PC_KC * 64 + 32;                              // bytes per weight row of a chunk (4 k-steps x 64 B + pad)
     constexpr int WBYTES = CG * WROW;
     constexpr int WSLOTS = (CG * PC_KC * 4 + PC_NT - 1) / PC_NT;       // 16-byte pieces of a chunk per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -80,16 +84,34 @@ __global__ __launch_bounds__(PC_NT, 1) void posconv_kernel(const PosConvParams p
         grow0[h] = p.row_off ? (long)p.row_off[clip[h]] : (long)clip[h] * p.T;
         if (rr >= Tc[h]) Tc[h] = 0;                                    // nothing of this half exists
     }
-    // ---- activation tiles -> LDS (bf16): row lr of half h = clip row r0 - pad + lr, zero outside [0, T)
+    // ---- activation tiles -> LDS (bf16): row lr of half h = clip row r0 - pad + lr, zero outside [0, T).  The loads of a batch of
+    //      slots are all issued before the first conversion (unconditional, from a clamped row: a load under `if` is waited for on the
+    //      spot, and 18 dependent global round trips per thread were a third of the kernel)
     {
         constexpr int C4 = CG / 4;
-        for (int idx = tid; idx < 2 * XROWS * C4; idx += PC_NT) {
-            const int h = idx / (XROWS * C4), rem = idx - h * (XROWS * C4);
-            const int lr = rem / C4, c4 = rem - lr * C4;
-            const int cr = r0[h] - p.pad + lr;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (cr >= 0 && cr < Tc[h]) v = *reinterpret_cast<const f32x4*>(p.x + (grow0[h] + cr) * p.H + g * CG + 4 * c4);
-            *reinterpret_cast<bf16x4*>(Xs + h * XBYTES + lr * RS + c4 * 8) = __builtin_convertvector(v, bf16x4);
+        constexpr int NSLOT = (2 * XROWS * C4 + PC_NT - 1) / PC_NT;
+        constexpr int BATCH = 12;
+#pragma unroll
+        for (int s0 = 0; s0 < NSLOT; s0 += BATCH) {
+            f32x4 v[BATCH];
+            bool ok[BATCH];
+            int dst[BATCH];
+#pragma unroll
+            for (int q = 0; q < BATCH; ++q) {
+                const int idx = tid + (s0 + q) * PC_NT;
+                const bool in_tile = s0 + q < NSLOT && idx < 2 * XROWS * C4;
+                const int ic = in_tile ? idx : 0;
+                const int h = ic / (XROWS * C4), rem = ic - h * (XROWS * C4);
+                const int lr = rem / C4, c4 = rem - lr * C4;
+                const int cr = r0[h] - p.pad + lr;
+                ok[q] = cr >= 0 && cr < Tc[h];
+                dst[q] = in_tile ? h * XBYTES + lr * RS + c4 * 8 : -1;
+                v[q] = *reinterpret_cast<const f32x4*>(p.x + (grow0[h] + (ok[q] ? cr : 0)) * p.H + g * CG + 4 * c4);
+            }
+#pragma unroll
+            for (int q = 0; q < BATCH; ++q) {
+                if (dst[q] >= 0) *reinterpret_cast<bf16x4*>(Xs + dst[q]) = __builtin_convertvector(ok[q] ? v[q] : f32x4{0.f, 0.f, 0.f, 0.f}, bf16x4);
+            }
         }
     }
     // ---- weight chunks: chunk c = flattened K elements [128 c, 128 c + 128) of every co: piece q of a thread = (co, 16-byte piece)
@@ -120,11 +142,8 @@ __global__ __launch_bounds__(PC_NT, 1) void posconv_kernel(const PosConvParams p
     if (nchunks > 1) issueW(1);
     __syncthreads();
 
-    // this wave's row tiles: 4 consecutive tiles of its half; a tile past the clip's rows is skipped (wave-uniform)
+    // this wave's row tiles: 4 consecutive tiles of its half
     const int tile0 = (wave & 3) * 4;
-    bool live[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) live[i] = r0[hsel] + (tile0 + i) * 16 < Tc[hsel];
     f32x4 acc[4][NTC];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -146,13 +165,12 @@ __global__ __launch_bounds__(PC_NT, 1) void posconv_kernel(const PosConvParams p
             const char* xp = xh + tap * RS + ci * 2;
 #pragma unroll
             for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(xp + i * 16 * RS);
+            // (every tile of the wave, also one past the clip's rows -- its LDS rows are zero: a per-tile `if` was compiled to exec-mask
+            //  branches between groups of three MFMAs, with a wait in front of each)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (live[i]) {
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < NTC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-                }
-            }
+                for (int j = 0; j < NTC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
             ci += 32;
             if (ci >= CG) { ci -= CG; ++tap; }
         }
@@ -183,7 +201,7 @@ __global__ __launch_bounds__(PC_NT, 1) void posconv_kernel(const PosConvParams p
 
 template <int CG>
 static int posconv_launch(si_ctx* ctx, const PosConvParams& p, int nwg, double rows, hipStream_t st) {
-    const size_t lds = 2 * (size_t)(PC_HALF_ROWS + 128) * (CG * 2 + 16) + 2 * (size_t)CG * (PC_KC * 64 + 16);
+    const size_t lds = 2 * (size_t)(PC_HALF_ROWS + 128) * (CG == 48 ? 96 : 160) + 2 * (size_t)CG * (PC_KC * 64 + 32);
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(posconv_kernel<CG>), lds)) return rc;
     char name[32];
     snprintf(name, sizeof(name), "posconv_bf16_c%d", CG);

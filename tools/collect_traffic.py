@@ -29,12 +29,22 @@ def family(kernel_name: str) -> str:
         return "gemm256_bf16"
     if "attention_bf16" in kernel_name:
         return "attention_bf16"
-    m = re.search(r"reschain_kernel<(\w+)>", kernel_name)
+    # the fused kernels end in <..., ACC, VL>: ACC = the accumulate variant (bench.py's "_acc"), VL = the ragged-batch instantiation
+    # (the same family name: bench.py times one or the other in a leg)
+    m = re.search(r"reschain_kernel<(true|false), (?:true|false)>", kernel_name)
     if m:      # bench.py's family name: reschain_f16_c32[_acc]
         return "reschain_f16_c32" + ("_acc" if m.group(1) == "true" else "")
-    m = re.search(r"respair(?:_wide)?_kernel<(\d+),.*?(true|false)>", kernel_name)
-    if m:      # bench.py's family name: respair_f16_c<C>[_acc] (the last template argument is the accumulate variant)
+    m = re.search(r"respair(?:_wide)?_kernel<(\d+),.*?(true|false), (?:true|false)>", kernel_name)
+    if m:      # bench.py's family name: respair_f16_c<C>[_acc]
         return f"respair_f16_c{m.group(1)}" + ("_acc" if m.group(2) == "true" else "")
+    m = re.search(r"posconv_kernel<(\d+)>", kernel_name)
+    if m:
+        return f"posconv_bf16_c{m.group(1)}"
+    m = re.search(r"upsample_stream_kernel<(\d+)", kernel_name)
+    if m:
+        return f"upsample_f16_c{m.group(1)}"
+    if "conv_post" in kernel_name:
+        return "conv_post"
     return re.sub(r"_kernel.*|\(.*", "", kernel_name).replace("void ", "")
 
 

@@ -82,6 +82,7 @@ struct si_ctx {
     // arithmetic-path options, read from the environment when the context is created (all default to 1)
     bool opt_voc_opready = true, opt_voc_res16 = true, opt_enc_opready = true, opt_att_bf16 = true, opt_enc_lingemm = true;
     bool opt_enc_posconv = true;             // the positional conv on posconv.hip in the bf16 encoder mode (SI_ENC_POSCONV=0: the generic tap-GEMM)
+    int opt_gemmcu = 1;                      // encoder GEMMs as one tile per CU (gemmcu.hip): 0 never, 1 by the shape rule, 2 whenever the shape allows, 10 + c (A/B)
     int opt_gemm256 = 1;                     // encoder GEMMs on 256 x 256 tiles: 0 never, 1 by the shape rule, 2 whenever the shape allows (tests)
     int opt_voc_chain = 1;                   // whole-resblock kernel on the C = 32 stage (SI_VOC_CHAIN=0: one launch per conv pair)
     int opt_voc_fuse = 1;                    // 0: never, 1: every covered width, otherwise a mask of the channel counts to fuse (32 | 64 | 128 | 256)
@@ -157,6 +158,7 @@ int si_ensure_dyn_lds(si_ctx* ctx, const void* kern, size_t bytes) {
     return SI_OK;
 }
 int si_opt_gemm256(const si_ctx* ctx) { return ctx->opt_gemm256; }
+int si_opt_gemmcu(const si_ctx* ctx) { return ctx->opt_gemmcu; }
 int si_num_cus(si_ctx* ctx) {
     if (ctx->num_cus <= 0) {
         int n = 0;
@@ -685,6 +687,7 @@ int si_create(si_ctx** out, int device_id, const si_model_desc* desc) {
     ctx->opt_enc_lingemm = env_flag("SI_ENC_LINGEMM");
     ctx->opt_enc_posconv = env_flag("SI_ENC_POSCONV");
     ctx->opt_gemm256 = getenv("SI_ENC_GEMM256") ? atoi(getenv("SI_ENC_GEMM256")) : 1;
+    ctx->opt_gemmcu = getenv("SI_ENC_GEMMCU") ? atoi(getenv("SI_ENC_GEMMCU")) : 1;
     plan_layout(ctx);
     *out = ctx;
     return SI_OK;

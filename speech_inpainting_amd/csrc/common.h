@@ -152,6 +152,11 @@ int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st);
 int si_launch_gemm256(si_ctx* ctx, const LinGemmParams& p, hipStream_t st);
 int si_opt_gemm256(const si_ctx* ctx);      // SI_ENC_GEMM256: 0 never, 1 by the shape rule (default), 2 whenever the shape allows
 
+// The same contract as ONE tile per CU (gemmcu.hip: 16 waves, tile shape per instantiation), for the flat M = B * T GEMMs of the
+// transformer whose tiles then number at most the CUs; returns 1 otherwise.  Bit-identical to the other two.
+int si_launch_gemmcu(si_ctx* ctx, const LinGemmParams& p, hipStream_t st);
+int si_opt_gemmcu(const si_ctx* ctx);       // SI_ENC_GEMMCU: 0 never, 1 by the shape rule (default), 2 whenever the shape allows, 10 + c: instantiation c
+
 // ------------------------------------------------------------------------------------------------
 // encoder kernels (encoder_kernels.hip)
 // ------------------------------------------------------------------------------------------------

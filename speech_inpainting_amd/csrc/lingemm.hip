@@ -273,7 +273,9 @@ int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     if (p.x_bytes <= 0 || p.w_bytes <= 0 || (long)p.nseg * p.x_seg_stride * 2 + (long)(p.M + 128) * p.lda * 2 >= (1L << 31)) return 1;
     if (!p.out && !p.out16) return si_fail(ctx, SI_EINVAL, "lingemm: no output");
     {
-        const int rc = si_launch_gemm256(ctx, p, st);                  // 256 x 256 tiles where they fill the chip (bit-identical results)
+        int rc = si_launch_gemmcu(ctx, p, st);                         // one tile per CU where that is one round of the chip (bit-identical results)
+        if (rc <= 0) return rc;
+        rc = si_launch_gemm256(ctx, p, st);                            // 256 x 256 tiles where they fill the chip (bit-identical results)
         if (rc <= 0) return rc;
     }
     // Tile height: the workgroup slots are 2 per CU; a launch takes ceil(tiles / slots) rounds of a tile's time, which

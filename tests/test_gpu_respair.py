@@ -227,6 +227,74 @@ def test_gemm256_persistent_walk_at_the_bench_shape():
     assert torch.equal(outs["1"], outs["0"])
 
 
+@pytest.mark.parametrize("arch,B,N,flag", [("base", 3, 24000, "10"), ("base", 3, 24000, "11"), ("base", 3, 24000, "12"), ("base", 3, 24000, "13"),
+                                           ("large", 2, 16000, "2"), ("base", 1, 64000, "2")])
+def test_gemmcu_matches_lingemm_in_the_bf16_encoder(arch, B, N, flag):
+    """The one-tile-per-CU GEMM (gemmcu.hip: 16 waves, LDS-DMA ring, tile shape per instantiation) against the 128-row kernels on the
+    same bf16 operands.  SI_ENC_GEMMCU=10 + c sends every shape instantiation c covers through it (320 x 256, 256 x 256, 160 x 128,
+    192 x 128: feature-extractor convolutions as per-clip segments with ragged last tiles, both projections, all four Linears of a
+    layer, fp32 + residual and bf16 outputs, GELU epilogues), =2 every shape through the instantiation the rule's cost picks, =0
+    none.  Same K order through the same MFMA with the same operand roles and epilogue: the encoder outputs must be EQUAL, run to
+    run as well (a race in the DMA ring would show as noise), and a clip must not depend on its batch neighbours."""
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import InpaintingEngine
+    harch = HubertArch.base() if arch == "base" else HubertArch.large()
+    varch = VocoderArch.tiny()
+    hsd, gsd, cb = synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook(50)
+    wave = synth.synth_wave(B, N, 97).cuda()
+    outs, engs = {}, {}
+    for f in (flag, "0"):
+        os.environ["SI_ENC_GEMMCU"] = f
+        os.environ["SI_ENC_GEMM256"] = "0"
+        try:
+            eng = InpaintingEngine(harch, varch, 50, "cuda:0", "bf16", "fp32").load_state(hsd, gsd, cb)
+        finally:
+            os.environ.pop("SI_ENC_GEMMCU", None)
+            os.environ.pop("SI_ENC_GEMM256", None)
+        eng.ctx.profile_start(4000)
+        outs[f] = eng.encode(wave).cpu()
+        names = {e["name"] for e in eng.ctx.profile_stop()}
+        assert any(n.startswith("gemmcu_bf16") for n in names) == (f != "0"), names
+        engs[f] = eng
+    again = [engs[flag].encode(wave).cpu() for _ in range(3)]
+    assert all(torch.equal(a, outs[flag]) for a in again)
+    if B > 1:
+        assert torch.equal(engs[flag].encode(wave[1:2].contiguous()).cpu(), outs[flag][1:2])
+    print(f"{arch} B={B} N={N} SI_ENC_GEMMCU={flag}: gemmcu == 128-row kernels: {torch.equal(outs[flag], outs['0'])}")
+    assert bool(torch.isfinite(outs[flag]).all())
+    assert torch.equal(outs[flag], outs["0"])
+
+
+def test_gemmcu_rule_at_the_bench_shape():
+    """B = 32 x 4 s (the bench's encoder, M = 6368 flat rows): the launcher's own rule puts the transformer's Linears and the feature
+    projection on one tile per CU (FFN1 on 320 x 256, the N = 768 GEMMs on 160 x 128); the features equal the run without
+    the kernel bit for bit, twice."""
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import InpaintingEngine
+    harch, varch = HubertArch.base(), VocoderArch.tiny()
+    hsd, gsd, cb = synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook(50)
+    wave = synth.synth_wave(32, 64000, 96).cuda()
+    outs = {}
+    for flag in ("1", "0"):
+        os.environ["SI_ENC_GEMMCU"] = flag
+        try:
+            eng = InpaintingEngine(harch, varch, 50, "cuda:0", "bf16", "fp32").load_state(hsd, gsd, cb)
+        finally:
+            os.environ.pop("SI_ENC_GEMMCU", None)
+        eng.ctx.profile_start(4000)
+        outs[flag] = eng.encode(wave).cpu()
+        prof = {e["name"]: e["launches"] for e in eng.ctx.profile_stop()}
+        cu = sum(v for k, v in prof.items() if k.startswith("gemmcu_bf16"))
+        if flag == "1":
+            assert cu >= 12 * 3, prof                                           # at least out-proj, FFN1, FFN2 of every layer
+            assert torch.equal(eng.encode(wave).cpu(), outs["1"])
+        else:
+            assert cu == 0, prof
+    assert torch.equal(outs["1"], outs["0"])
+
+
 @pytest.mark.parametrize("scale", [0.125, 1.0, 8.0])
 def test_fp16_vocoder_across_activation_scales(scale):
     """The fp16 activation stream at other operating points than the synthetic checkpoint's: `conv_pre` scaled by 1/8 and 8 (the

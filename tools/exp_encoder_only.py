@@ -42,3 +42,10 @@ if "timeline" in os.environ.get("SI_HIP_LIB", ""):
             print(f"  gemm256 timeline, {nm}: {v[3]} tiles on {v[4]} workgroup launches; per workgroup: prologue {v[0] / v[4] * 0.01:.2f} us, "
                   f"K loops {v[1] / v[4] * 0.01:.2f} us ({v[1] / max(v[3], 1) * 0.01:.2f} per tile), epilogues {v[2] / v[4] * 0.01:.2f} us "
                   f"({v[2] / max(v[3], 1) * 0.01:.2f} per tile), whole kernel {v[5] / v[4] * 0.01:.2f} us")
+    out = (ctypes.c_ulonglong * 16)()
+    if hasattr(eng.ctx.lib, "si_debug_gcu_timeline") and eng.ctx.lib.si_debug_gcu_timeline(out, 1) == 0:
+        for c, nm in enumerate(("N=3072 (FFN1)", "N=2304 (QKV)", "N=768 K=3072 (FFN2)", "other")):
+            v = out[4 * c:4 * c + 4]
+            if v[3]:
+                print(f"  gemmcu timeline, {nm}: {v[3]} workgroups; per workgroup: prologue {v[0] / v[3] * 0.01:.2f} us, K loop {v[1] / v[3] * 0.01:.2f} us, "
+                      f"epilogue (stores drained) {v[2] / v[3] * 0.01:.2f} us")

@@ -11,9 +11,9 @@
 // takes the tile shape as a template parameter and the launcher picks, per shape, the instantiation whose tiles number at most the
 // CUs and draw the fewest bytes: 320 x 256 (FFN1: 20 x 12 = 240 tiles), 256 x 256 (QKV: 225), 160 x 128 (N = 768: 40 x 6 = 240).
 //
-// Structure.  1024 threads = 16 waves as WM (M) x WN (N); a wave owns (16 MT) x (16 NT) outputs; one workgroup per CU.  Four waves
-// per SIMD (<= 128 registers each) let the hardware interleave one wave's fragment reads with its neighbours' MFMAs -- no hand-made
-// partner schedule as in gemm256.hip, whose 8 waves hold a whole K-tile's fragments.  K-tiles of 64 (whole 128-byte lines of every
+// Structure.  NW waves (16 for the 256-column tiles, 8 for 160 x 128) as WM (M) x WN (N); a wave owns (16 MT) x (16 NT) outputs; one
+// workgroup per CU.  Four waves per SIMD (<= 128 registers each) let the hardware interleave one wave's fragment reads with its
+// neighbours' MFMAs -- no hand-made partner schedule as in gemm256.hip, whose 8 waves hold a whole K-tile's fragments.  K-tiles of 64 (whole 128-byte lines of every
 // operand row) arrive by LDS-DMA (buffer_load_dwordx4 ... lds, the XOR swizzle of lingemm.hip applied on the source side) into a
 // ring of NS stages of (BM + BN) x 128 bytes; iteration t = [counted vmcnt: own pieces of K-tile t landed | barrier: everyone's
 // landed, everyone done reading K-tile t - 1 | request K-tile t + NS - 1 into the stage K-tile t - 1 occupied | 2 k-steps of
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(NW * 64) void gemmcu_kernel(const LinGemmParams p) 
 }
 
 struct CuCfg { int bm, bn, ns; };
-static const CuCfg k_cfgs[] = {{320, 256, 2}, {256, 256, 2}, {160, 128, 4}, {192, 128, 3}, {160, 128, 4}, {320, 256, 2}, {256, 256, 2}, {160, 128, 4}};
-constexpr int k_ncfg = 8, k_nrule = 4;                                  // the rule chooses among the first k_nrule
+static const CuCfg k_cfgs[] = {{320, 256, 2}, {256, 256, 2}, {160, 128, 4}};
+constexpr int k_ncfg = 3, k_nrule = 3;
 
 template <int NW, int WM, int WN, int MT, int NT, int NS>
 static int gemmcu_launch(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
@@ -254,7 +254,7 @@ static int gemmcu_launch(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     const double outs = rows_real * p.N;
     const double bytes = 2.0 * (rows_real * p.lda + p.nseg * (double)(p.K - p.lda > 0 ? p.K - p.lda : 0)) + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0)) + 2.0 * p.N * p.K;
     char name[48];
-    if (NW == 16) snprintf(name, sizeof(name), "gemmcu_bf16_%dx%d", BM, BN); else snprintf(name, sizeof(name), "gemmcu_bf16_%dx%dw%d", BM, BN, NW);        // one family per instantiation, as rocprofv3 lists them
+    snprintf(name, sizeof(name), "gemmcu_bf16_%dx%d", BM, BN);        // one family per instantiation, as rocprofv3 lists them
     si_prof_begin(ctx, si_prof_shape_name(name, p.M * (long)p.nseg, p.N, p.K), 2.0 * macs, bytes, st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, q);
     si_prof_end(ctx, st);
@@ -279,26 +279,23 @@ int si_launch_gemmcu(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
         if (pick >= k_ncfg || p.N % k_cfgs[pick].bn) return 1;
     } else {
         // One round of the chip: among the instantiations whose tiles number at most the CUs, the one whose tile draws the fewest
-        // operand bytes per CU ((BM + BN) rows of K); it must also fill the chip (tiles >= 0.7 CUs: below that the 128-row kernels'
-        // two workgroups per CU spread the same bytes over more L1s).  opt == 2 drops both conditions.
+        // operand bytes per CU ((BM + BN) rows of K).  It must also fill the chip -- tiles >= 0.6 CUs (below that the 128-row
+        // kernels' two workgroups per CU spread the same bytes over more L1s: HuBERT-large's N = 1024 GEMMs at B = 16) and at
+        // least 3/4 of the tiles' rows real (per-clip segments of 199 rows on 160-row tiles are not).  opt == 2 drops the conditions.
         double best = 1e30;
         for (int c = 0; c < k_nrule; ++c) {
             if (p.N % k_cfgs[c].bn) continue;
-            const long tiles = (long)p.nseg * ((p.M + k_cfgs[c].bm - 1) / k_cfgs[c].bm) * (p.N / k_cfgs[c].bn);
-            if (opt == 1 && (tiles > cus || tiles * 10 < cus * 7)) continue;
+            const long rb = (long)p.nseg * ((p.M + k_cfgs[c].bm - 1) / k_cfgs[c].bm);
+            const long tiles = rb * (p.N / k_cfgs[c].bn);
+            if (opt == 1 && (tiles > cus || tiles * 10 < cus * 6 || (double)p.nseg * p.M < 0.75 * (double)rb * k_cfgs[c].bm)) continue;
             const double cost = (double)((tiles + cus - 1) / cus) * (k_cfgs[c].bm + k_cfgs[c].bn);
             if (cost < best) { best = cost; pick = c; }
         }
         if (pick < 0) return 1;
     }
     switch (pick) {
-        case 0: return gemmcu_launch<16, 4, 4, 5, 4, 2>(ctx, p, st);
-        case 1: return gemmcu_launch<16, 4, 4, 4, 4, 2>(ctx, p, st);
-        case 2: return gemmcu_launch<16, 2, 8, 5, 1, 4>(ctx, p, st);
-        case 3: return gemmcu_launch<16, 4, 4, 3, 2, 3>(ctx, p, st);
-        case 4: return gemmcu_launch<8, 2, 4, 5, 2, 4>(ctx, p, st);
-        case 5: return gemmcu_launch<8, 2, 4, 10, 4, 2>(ctx, p, st);
-        case 6: return gemmcu_launch<8, 2, 4, 8, 4, 2>(ctx, p, st);
-        default: return gemmcu_launch<4, 2, 2, 5, 4, 4>(ctx, p, st);
+        case 0: return gemmcu_launch<16, 4, 4, 5, 4, 2>(ctx, p, st);     // 320 x 256, 16 waves of 80 x 64
+        case 1: return gemmcu_launch<16, 4, 4, 4, 4, 2>(ctx, p, st);     // 256 x 256, 16 waves of 64 x 64
+        default: return gemmcu_launch<8, 2, 4, 5, 2, 4>(ctx, p, st);     // 160 x 128, 8 waves of 80 x 32, four-stage ring
     }
 }

@@ -82,6 +82,8 @@ struct si_ctx {
     // arithmetic-path options, read from the environment when the context is created (all default to 1)
     bool opt_voc_opready = true, opt_voc_res16 = true, opt_enc_opready = true, opt_att_bf16 = true, opt_enc_lingemm = true;
     bool opt_enc_posconv = true;             // the positional conv on posconv.hip in the bf16 encoder mode (SI_ENC_POSCONV=0: the generic tap-GEMM)
+    int opt_ffn_pad = 64;                    // elements of padding behind each row of the bf16 FFN intermediate (SI_ENC_FFNPAD; multiple of 8, <= 128):
+                                             // rows 6144 bytes apart are 6272 apart instead -- FFN2 -1.5 % (profiles/r04_ffnpad_ab.txt), same values
     int opt_gemmcu = 1;                      // encoder GEMMs as one tile per CU (gemmcu.hip): 0 never, 1 by the shape rule, 2 whenever the shape allows, 10 + c (A/B)
     int opt_gemm256 = 1;                     // encoder GEMMs on 256 x 256 tiles: 0 never, 1 by the shape rule, 2 whenever the shape allows (tests)
     int opt_voc_chain = 1;                   // whole-resblock kernel on the C = 32 stage (SI_VOC_CHAIN=0: one launch per conv pair)
@@ -603,7 +605,7 @@ size_t encoder_ws_bytes(const si_model_desc& d, int B, int N) {
     size_t f = 2 * (size_t)B * cmax + BT * d.conv_dim[d.num_conv - 1] + BT * d.hidden_size * 3 + BT * 3 * d.hidden_size + BT * d.intermediate_size +
                (size_t)B * d.conv_dim[0] * 2;
     // bf16 operand-ready copies (encoder in bf16 mode): LN(features), hidden, attention output, FFN intermediate
-    const size_t h16 = (BT * d.conv_dim[d.num_conv - 1] + 2 * BT * d.hidden_size + BT * d.intermediate_size) * 2;
+    const size_t h16 = (BT * d.conv_dim[d.num_conv - 1] + 2 * BT * d.hidden_size + BT * (d.intermediate_size + 128)) * 2;   // (+ the row padding of the FFN intermediate)
     return f * 4 + h16 + (size_t)B * 16 + (size_t)B * 4 + si_conv0_partials_bytes(B, N) + 41 * 256 +
            align_up((size_t)(SI_MAX_CONV + 3) * (B + 1) * 4, 256);    // ragged batches: per-layer length table + row offsets
 }
@@ -641,12 +643,13 @@ TapGemmParams gemm_params(const si_ctx* ctx, const GemmW& G) {
 
 // y(rows x N) = x(rows x K) W^T + b [+act] [+res]
 // x16 / y16: operand-ready bf16 input (instead of x) / additional-or-only bf16 output, see TapGemmParams
+// ld_in / ld_out (elements; 0 = dense): row strides of the 16-bit input / of the output when they are padded (the FFN intermediate)
 int linear(si_ctx* ctx, const GemmW& G, const float* x, float* y, long rows, int act, const float* res, hipStream_t st,
-           const unsigned short* x16 = nullptr, unsigned short* y16 = nullptr) {
+           const unsigned short* x16 = nullptr, unsigned short* y16 = nullptr, int ld_in = 0, int ld_out = 0) {
     TapGemmParams p = gemm_params(ctx, G);
     p.x = x16 ? nullptr : x; p.x16 = x16; p.out = y; p.out16 = y16; p.res = res; p.act = act;
-    p.nseg = 1; p.Lin = (int)rows; p.M = (int)rows; p.ldx = G.Cin; p.x_seg_stride = 0;
-    p.ldo = G.N; p.o_seg_stride = 0; p.ooff = 0; p.olimit = rows * G.N;
+    p.nseg = 1; p.Lin = (int)rows; p.M = (int)rows; p.ldx = ld_in ? ld_in : G.Cin; p.x_seg_stride = 0;
+    p.ldo = ld_out ? ld_out : G.N; p.o_seg_stride = 0; p.ooff = 0; p.olimit = rows * p.ldo;
     p.lingemm = ctx->opt_enc_lingemm;
     return si_launch_tapgemm(ctx, G.math, p, st);
 }
@@ -688,6 +691,7 @@ int si_create(si_ctx** out, int device_id, const si_model_desc* desc) {
     ctx->opt_enc_posconv = env_flag("SI_ENC_POSCONV");
     ctx->opt_gemm256 = getenv("SI_ENC_GEMM256") ? atoi(getenv("SI_ENC_GEMM256")) : 1;
     ctx->opt_gemmcu = getenv("SI_ENC_GEMMCU") ? atoi(getenv("SI_ENC_GEMMCU")) : 1;
+    ctx->opt_ffn_pad = getenv("SI_ENC_FFNPAD") ? std::min(128, std::max(0, atoi(getenv("SI_ENC_FFNPAD")) / 8 * 8)) : 64;
     plan_layout(ctx);
     *out = ctx;
     return SI_OK;
@@ -893,7 +897,8 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     unsigned short* lnf16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * CF * 2)) : nullptr;
     unsigned short* h16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * H * 2)) : nullptr;
     unsigned short* att16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * H * 2)) : nullptr;
-    unsigned short* ffn16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * I * 2)) : nullptr;
+    const int ffn_ld = e16 ? I + ctx->opt_ffn_pad : I;                 // row stride of the bf16 FFN intermediate (SI_ENC_FFNPAD)
+    unsigned short* ffn16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * ffn_ld * 2)) : nullptr;
     if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: encoder workspace carve exceeded its own estimate");
     // bf16 mode with the bf16-MFMA attention: the QKV GEMM writes q | k | v as bf16 only (the rounding the attention
     // kernel's staging would apply), into the storage of the fp32 matrix
@@ -1012,8 +1017,8 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
             if (rc) return rc;
             if ((rc = linear(ctx, Wl.out, att, h2, BT, SI_ACT_NONE, h, st, att16))) return rc;
             if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h, BT, H, eps, 0, st, h16))) return rc;
-            if ((rc = linear(ctx, Wl.ffn1, h, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16))) return rc;
-            if ((rc = linear(ctx, Wl.ffn2, ffn, h2, BT, SI_ACT_NONE, h, st, ffn16))) return rc;
+            if ((rc = linear(ctx, Wl.ffn1, h, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16, 0, e16 ? ffn_ld : 0))) return rc;
+            if ((rc = linear(ctx, Wl.ffn2, ffn, h2, BT, SI_ACT_NONE, h, st, ffn16, nullptr, e16 ? ffn_ld : 0))) return rc;
             if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h, BT, H, eps, 0, st, h16))) return rc;
         } else {                          // pre-LN "stable" (modeling_hubert.py:504-547); residual adds are in place
             if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h2, BT, H, eps, 0, st, h16))) return rc;
@@ -1023,8 +1028,8 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
             if (rc) return rc;
             if ((rc = linear(ctx, Wl.out, att, h, BT, SI_ACT_NONE, h, st, att16))) return rc;
             if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h2, BT, H, eps, 0, st, h16))) return rc;
-            if ((rc = linear(ctx, Wl.ffn1, h2, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16))) return rc;
-            if ((rc = linear(ctx, Wl.ffn2, ffn, h, BT, SI_ACT_NONE, h, st, ffn16))) return rc;
+            if ((rc = linear(ctx, Wl.ffn1, h2, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16, 0, e16 ? ffn_ld : 0))) return rc;
+            if ((rc = linear(ctx, Wl.ffn2, ffn, h, BT, SI_ACT_NONE, h, st, ffn16, nullptr, e16 ? ffn_ld : 0))) return rc;
         }
         if (output_layer == l + 1) {
             // fairseq `extract_features(output_layer = L)` (I_da/src/hubert_feature_reader.py:60-65): the loop stops after layer

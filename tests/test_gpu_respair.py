@@ -269,6 +269,26 @@ def test_gemmcu_matches_lingemm_in_the_bf16_encoder(arch, B, N, flag):
     assert torch.equal(outs[flag], outs["0"])
 
 
+def test_ffn_row_padding_changes_no_value():
+    """SI_ENC_FFNPAD: the bf16 FFN intermediate is stored with padded rows (default 64 elements: FFN2's operand rows then start
+    6272 instead of 6144 bytes apart); a layout choice only -- the encoder output equals the dense layout's bit for bit."""
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import InpaintingEngine
+    harch, varch = HubertArch.base(), VocoderArch.tiny()
+    hsd, gsd, cb = synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook(50)
+    wave = synth.synth_wave(5, 40000, 98).cuda()
+    outs = {}
+    for pad in ("0", "64", "128"):
+        os.environ["SI_ENC_FFNPAD"] = pad
+        try:
+            eng = InpaintingEngine(harch, varch, 50, "cuda:0", "bf16", "fp32").load_state(hsd, gsd, cb)
+        finally:
+            os.environ.pop("SI_ENC_FFNPAD", None)
+        outs[pad] = eng.encode(wave).cpu()
+    assert torch.equal(outs["0"], outs["64"]) and torch.equal(outs["0"], outs["128"])
+
+
 def test_gemmcu_rule_at_the_bench_shape():
     """B = 32 x 4 s (the bench's encoder, M = 6368 flat rows): the launcher's own rule puts the transformer's Linears and the feature
     projection on one tile per CU (FFN1 on 320 x 256, the N = 768 GEMMs on 160 x 128); the features equal the run without

@@ -299,17 +299,21 @@ int si_launch_gemmcu(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
         pick = opt - 10;
         if (pick >= k_ncfg || p.N % k_cfgs[pick].bn) return 1;
     } else {
-        // One round of the chip: among the instantiations whose tiles number at most the CUs, the one whose tile draws the fewest
-        // operand bytes per CU ((BM + BN) rows of K).  It must also fill the chip -- tiles >= 0.6 CUs (below that the 128-row
-        // kernels' two workgroups per CU spread the same bytes over more L1s: HuBERT-large's N = 1024 GEMMs at B = 16) and at
-        // least 3/4 of the tiles' rows real (per-clip segments of 199 rows on 160-row tiles are not).  opt == 2 drops the conditions.
+        // Whole rounds of the chip: among the instantiations whose tiles fill their rounds -- tiles / (rounds x CUs) >= 0.6 for one
+        // round (below that the 128-row kernels' two workgroups per CU spread the same bytes over more L1s: HuBERT-large's N = 1024
+        // GEMMs at B = 16), >= 0.75 for several -- and whose rows are at least 3/4 real (per-clip segments of 199 rows on 160-row
+        // tiles are not), the one with the fewest operand bytes per CU: rounds x (BM + BN) rows of K.  The feature extractor's
+        // convolutions are several rounds (conv1: 1280 tiles of 320 x 256 = 5.0 rounds, against 6.25 of 256 x 256); the
+        // transformer's GEMMs one.  opt == 2 drops the conditions.
         double best = 1e30;
         for (int c = 0; c < k_nrule; ++c) {
             if (p.N % k_cfgs[c].bn) continue;
             const long rb = (long)p.nseg * ((p.M + k_cfgs[c].bm - 1) / k_cfgs[c].bm);
             const long tiles = rb * (p.N / k_cfgs[c].bn);
-            if (opt == 1 && (tiles > cus || tiles * 10 < cus * 6 || (double)p.nseg * p.M < 0.75 * (double)rb * k_cfgs[c].bm)) continue;
-            const double cost = (double)((tiles + cus - 1) / cus) * (k_cfgs[c].bm + k_cfgs[c].bn);
+            const long rounds = (tiles + cus - 1) / cus;
+            const double fill = (double)tiles / (double)(rounds * cus);
+            if (opt == 1 && (fill < (rounds == 1 ? 0.6 : 0.75) || (double)p.nseg * p.M < 0.75 * (double)rb * k_cfgs[c].bm)) continue;
+            const double cost = (double)rounds * (k_cfgs[c].bm + k_cfgs[c].bn);
             if (cost < best) { best = cost; pick = c; }
         }
         if (pick < 0) return 1;

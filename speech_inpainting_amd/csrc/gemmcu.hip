@@ -98,8 +98,14 @@ __global__ __launch_bounds__(NW * 64) void gemmcu_kernel(const LinGemmParams p) 
     const int tile = run0 + slot;
     if (tile >= run1) return;
     const int mtx = tile / ntn;
-    const int seg = mtx / mtiles;
-    const int m0 = (mtx - seg * mtiles) * BM;
+    int seg, m0, Ms = p.M;
+    if (p.seg_m) {                                                     // ragged batches: row blocks numbered segment by segment without gaps
+        const SiVlTile v = si_vl_tile(p.seg_m, p.nseg, BM, mtx);
+        seg = v.b; m0 = v.row0; Ms = v.L;
+    } else {
+        seg = mtx / mtiles;
+        m0 = (mtx - seg * mtiles) * BM;
+    }
     const int n0 = (tile - mtx * ntn) * BN;
 
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.x16), 0, p.x_bytes, 0x00020000);
@@ -199,8 +205,8 @@ __global__ __launch_bounds__(NW * 64) void gemmcu_kernel(const LinGemmParams p) 
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = m0 + wr * MT * 16 + 16 * i + r16;
-        const bool live = m < p.M;
-        const long orow = obase + (long)(live ? m : p.M - 1) * p.ldo + ncol0;      // dead rows read row M - 1 and store nothing
+        const bool live = m < Ms;
+        const long orow = obase + (long)(live ? m : Ms - 1) * p.ldo + ncol0;      // dead rows read row M - 1 and store nothing
         f32x4 rv[NT];
         if (has_res) {
 #pragma unroll
@@ -258,10 +264,12 @@ static int gemmcu_launch(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), lds)) return rc;
     LinGemmParams q = p;
     const int mtiles = (p.M + BM - 1) / BM;
-    const int tiles = p.nseg * mtiles * (p.N / BN);
+    const long row_blocks = p.seg_m_host ? si_vl_tiles(p.seg_m_host, p.nseg, BM) : (long)p.nseg * mtiles;   // ragged batches: no gaps
+    const int tiles = (int)(row_blocks * (p.N / BN));
     q.xcd_rows = tiles;
     const unsigned grid = (unsigned)((tiles + 7) / 8 * 8);
-    const double rows_real = (double)p.nseg * p.M;
+    double rows_real = (double)p.nseg * p.M;
+    if (p.seg_m_host) { rows_real = 0; for (int sg = 0; sg < p.nseg; ++sg) rows_real += p.seg_m_host[sg]; }
     const double macs = rows_real * p.N * (double)p.K;
     const double outs = rows_real * p.N;
     const double bytes = 2.0 * (rows_real * p.lda + p.nseg * (double)(p.K - p.lda > 0 ? p.K - p.lda : 0)) + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0)) + 2.0 * p.N * p.K;
@@ -289,11 +297,13 @@ static int gemmcu_launch(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
 int si_launch_gemmcu(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     const int opt = si_opt_gemmcu(ctx);
     if (opt == 0) return 1;
-    if (p.seg_m || p.seg_m_host) return 1;                             // ragged segments: lingemm / gemm256 (the transformer's GEMMs are one flat segment)
+    if (p.seg_m && !p.seg_m_host) return 1;                            // ragged segments need their host copy for the grid
     if (p.Cin % C_BK || p.K % C_BK || p.K != p.ntaps * p.Cin || p.ldo % 4 || p.lda % 8 || p.M <= 0 || p.nseg <= 0 || p.N % 128) return 1;
     if (p.x_bytes <= 0 || p.w_bytes <= 0 || (long)p.nseg * p.x_seg_stride * 2 + (long)(p.M + 320) * p.lda * 2 >= (1L << 31)) return 1;
     if ((long)(p.N + 256) * p.Cin * 2 + (long)p.ntaps * p.w_tap_stride * 2 >= (1L << 31)) return 1;
     const int cus = si_num_cus(ctx);
+    double rows_real = (double)p.nseg * p.M;
+    if (p.seg_m_host) { rows_real = 0; for (int sg = 0; sg < p.nseg; ++sg) rows_real += p.seg_m_host[sg]; }
     int pick = -1;
     if (opt >= 10) {
         pick = opt - 10;
@@ -308,11 +318,12 @@ int si_launch_gemmcu(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
         double best = 1e30;
         for (int c = 0; c < k_nrule; ++c) {
             if (p.N % k_cfgs[c].bn) continue;
-            const long rb = (long)p.nseg * ((p.M + k_cfgs[c].bm - 1) / k_cfgs[c].bm);
+            const long rb = p.seg_m_host ? si_vl_tiles(p.seg_m_host, p.nseg, k_cfgs[c].bm) : (long)p.nseg * ((p.M + k_cfgs[c].bm - 1) / k_cfgs[c].bm);
+            if (rb <= 0) continue;
             const long tiles = rb * (p.N / k_cfgs[c].bn);
             const long rounds = (tiles + cus - 1) / cus;
             const double fill = (double)tiles / (double)(rounds * cus);
-            if (opt == 1 && (fill < (rounds == 1 ? 0.6 : 0.75) || (double)p.nseg * p.M < 0.75 * (double)rb * k_cfgs[c].bm)) continue;
+            if (opt == 1 && (fill < (rounds == 1 ? 0.6 : 0.75) || rows_real < 0.75 * (double)rb * k_cfgs[c].bm)) continue;
             const double cost = (double)rounds * (k_cfgs[c].bm + k_cfgs[c].bn);
             if (cost < best) { best = cost; pick = c; }
         }

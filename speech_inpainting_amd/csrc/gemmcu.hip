@@ -253,8 +253,8 @@ __global__ __launch_bounds__(NW * 64) void gemmcu_kernel(const LinGemmParams p) 
 }
 
 struct CuCfg { int bm, bn, ns; };
-static const CuCfg k_cfgs[] = {{320, 256, 2}, {256, 256, 2}, {160, 128, 4}, {224, 128, 3}, {128, 128, 4}};
-constexpr int k_ncfg = 5, k_nrule = 5;
+static const CuCfg k_cfgs[] = {{320, 256, 2}, {256, 256, 2}, {160, 128, 4}, {224, 128, 3}, {128, 128, 4}, {208, 256, 2}};
+constexpr int k_ncfg = 6, k_nrule = 6;
 
 template <int NW, int WM, int WN, int MT, int NT, int NS>
 static int gemmcu_launch(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
@@ -334,6 +334,7 @@ int si_launch_gemmcu(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
         case 1: return gemmcu_launch<16, 4, 4, 4, 4, 2>(ctx, p, st);     // 256 x 256, 16 waves of 64 x 64
         case 2: return gemmcu_launch<8, 2, 4, 5, 2, 4>(ctx, p, st);      // 160 x 128, 8 waves of 80 x 32, four-stage ring
         case 3: return gemmcu_launch<8, 2, 4, 7, 2, 3>(ctx, p, st);      // 224 x 128, 8 waves of 112 x 32 (HuBERT-large's N = 1024 GEMMs at M = 6368)
-        default: return gemmcu_launch<8, 2, 4, 4, 2, 4>(ctx, p, st);     // 128 x 128, 8 waves of 64 x 32 (the same at M = 3184)
+        case 4: return gemmcu_launch<8, 2, 4, 4, 2, 4>(ctx, p, st);      // 128 x 128, 8 waves of 64 x 32 (the same at M = 3184)
+        default: return gemmcu_launch<8, 1, 8, 13, 2, 2>(ctx, p, st);    // 208 x 256, 8 waves of 208 x 32 (HuBERT-large's FFN1: N = 4096 at M = 6368 / 3184)
     }
 }

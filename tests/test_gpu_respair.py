@@ -231,11 +231,11 @@ def test_gemm256_persistent_walk_at_the_bench_shape():
     assert torch.equal(outs["1"], outs["0"])
 
 
-@pytest.mark.parametrize("arch,B,N,flag", [("base", 3, 24000, "10"), ("base", 3, 24000, "11"), ("base", 3, 24000, "12"), ("base", 3, 24000, "13"), ("large", 2, 16000, "14"),
+@pytest.mark.parametrize("arch,B,N,flag", [("base", 3, 24000, "10"), ("base", 3, 24000, "11"), ("base", 3, 24000, "12"), ("base", 3, 24000, "13"), ("large", 2, 16000, "14"), ("large", 2, 16000, "15"),
                                            ("large", 2, 16000, "2"), ("base", 1, 64000, "2")])
 def test_gemmcu_matches_lingemm_in_the_bf16_encoder(arch, B, N, flag):
     """The one-tile-per-CU GEMM (gemmcu.hip: 16 waves, LDS-DMA ring, tile shape per instantiation) against the 128-row kernels on the
-    same bf16 operands.  SI_ENC_GEMMCU=10 + c sends every shape instantiation c covers through it (320 x 256, 256 x 256, 160 x 128, 224 x 128, 128 x 128: feature-extractor convolutions as per-clip segments with ragged last tiles, both projections, all four Linears of a
+    same bf16 operands.  SI_ENC_GEMMCU=10 + c sends every shape instantiation c covers through it (320 x 256, 256 x 256, 160 x 128, 224 x 128, 128 x 128, 208 x 256: feature-extractor convolutions as per-clip segments with ragged last tiles, both projections, all four Linears of a
     layer, fp32 + residual and bf16 outputs, GELU epilogues), =2 every shape through the instantiation the rule's cost picks, =0
     none.  Same K order through the same MFMA with the same operand roles and epilogue: the encoder outputs must be EQUAL, run to
     run as well (a race in the DMA ring would show as noise), and a clip must not depend on its batch neighbours."""

@@ -82,6 +82,7 @@ struct si_ctx {
     // arithmetic-path options, read from the environment when the context is created (all default to 1)
     bool opt_voc_opready = true, opt_voc_res16 = true, opt_enc_opready = true, opt_att_bf16 = true, opt_enc_lingemm = true;
     bool opt_enc_posconv = true;             // the positional conv on posconv.hip in the bf16 encoder mode (SI_ENC_POSCONV=0: the generic tap-GEMM)
+    int opt_voc_upsgemm = 1;                 // the generator's early upsamplers on gemmcu.hip's TC instantiations (SI_VOC_UPSGEMM=0: the tap-GEMM)
     int opt_ffn_pad = 64;                    // elements of padding behind each row of the bf16 FFN intermediate (SI_ENC_FFNPAD; multiple of 8, <= 128):
                                              // rows 6144 bytes apart are 6272 apart instead -- FFN2 -1.5 % (profiles/r04_ffnpad_ab.txt), same values
     int opt_gemmcu = 1;                      // encoder GEMMs as one tile per CU (gemmcu.hip): 0 never, 1 by the shape rule, 2 whenever the shape allows, 10 + c (A/B)
@@ -691,6 +692,7 @@ int si_create(si_ctx** out, int device_id, const si_model_desc* desc) {
     ctx->opt_enc_posconv = env_flag("SI_ENC_POSCONV");
     ctx->opt_gemm256 = getenv("SI_ENC_GEMM256") ? atoi(getenv("SI_ENC_GEMM256")) : 1;
     ctx->opt_gemmcu = getenv("SI_ENC_GEMMCU") ? atoi(getenv("SI_ENC_GEMMCU")) : 1;
+    ctx->opt_voc_upsgemm = getenv("SI_VOC_UPSGEMM") ? atoi(getenv("SI_VOC_UPSGEMM")) : 1;
     ctx->opt_ffn_pad = getenv("SI_ENC_FFNPAD") ? std::min(128, std::max(0, atoi(getenv("SI_ENC_FFNPAD")) / 8 * 8)) : 64;
     plan_layout(ctx);
     *out = ctx;
@@ -1389,6 +1391,22 @@ static int hifigan_run(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
         auto seg_conv = [&](TapGemmParams& q, int sidx) { if (vl) { q.seg_lin = q.seg_m = q.seg_orows = dLs(sidx); q.olim_mul = q.ldo; q.seg_m_host = hLs(sidx); } };
         // A14: stretch + transpose to channels-last
         if ((rc = si_launch_extend_mel(ctx, mel + (size_t)b0 * d.num_mels * Tm, Bc, d.num_mels, Tm, (int)Tout, stretch, ext, Ly.mel_ld, st, dTm, dLs(0)))) return rc;
+        // Will upsampler i run on gemmcu.hip's TC instantiations?  Its producer (conv_pre / the last launch of the previous stage's MRF
+        // sum) then stores leaky_relu(x, 0.1) -- the upsampler's own first statement (models.py:110) applied once to the fp32 value
+        // instead of to every fragment it is read into -- and the upsampler takes its input as it is.
+        auto ups_on_gemmcu = [&](int i, long Lc_i, int c_i) -> bool {
+            if (!r16 || !ctx->opt_voc_upsgemm || i >= d.num_ups) return false;
+            const GemmW& G = Ly.ups[i];
+            if (G.math != SI_MATH_F16 || !G.has_bias) return false;
+            const int u = d.up_rates[i], k = d.up_kernels[i], cout = stage_channels(ctx, i), pad = (k - u) / 2;
+            const long Lo_i = Lc_i * u;
+            TapGemmParams p = gemm_params(ctx, G);
+            p.x16 = h16[0]; p.out16 = h16[2]; p.out16_slope = 1.f;
+            p.nseg = Bc; p.Lin = (int)Lc_i; p.M = (int)((pad + Lo_i - 1) / u + 1); p.ldx = c_i; p.x_seg_stride = Lc_i * c_i;
+            p.dil = -1; p.ldo = u * cout; p.o_seg_stride = Lo_i * cout; p.ooff = -(long)pad * cout; p.olimit = Lo_i * cout; p.pro_slope = 0.1f;
+            if (vl) { p.seg_lin = dLs(i); p.seg_m = dMt(i); p.seg_orows = dLs(i + 1); p.olim_mul = cout; p.seg_m_host = hMt(i); }
+            return si_gemmcu_tc_covers(ctx, p, true);                 // by the layer's geometry alone: a clip's samples must not depend on its batch
+        };
         // B1: conv_pre
         float* x = buf[0];
         float* xs = buf[1];
@@ -1396,7 +1414,7 @@ static int hifigan_run(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
         {
             TapGemmParams p = gemm_params(ctx, Ly.pre);
             p.x = ext; p.out = x;
-            if (opr) { p.out16 = x16; p.out16_slope = r16 ? 1.f : 0.1f; }
+            if (opr) { p.out16 = x16; p.out16_slope = (r16 && !ups_on_gemmcu(0, Tout, d.up_initial_channel)) ? 1.f : 0.1f; }
             if (r16) p.out = nullptr;
             p.nseg = Bc; p.Lin = (int)Tout; p.M = (int)Tout; p.ldx = Ly.mel_ld; p.x_seg_stride = Tout * Ly.mel_ld;
             p.algo_macs = rows_of(hLs(0), Tout) * d.up_initial_channel * (double)d.num_mels * 7;
@@ -1432,13 +1450,20 @@ static int hifigan_run(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                 if (r16) p.out = nullptr;
                 p.nseg = Bc; p.Lin = (int)Lc; p.M = (int)((pad + Lo - 1) / u + 1); p.ldx = c; p.x_seg_stride = Lc * c;
                 p.dil = -1; p.ldo = u * cout; p.o_seg_stride = Lo * cout; p.ooff = -(long)pad * cout; p.olimit = Lo * cout;
-                p.pro_slope = (opr && !r16) ? 1.f : 0.1f;          // operand-ready inputs are already activated
+                const bool pre_act = ups_on_gemmcu(i, Lc, c);       // (its producer stored the activated input)
+                p.pro_slope = ((opr && !r16) || pre_act) ? 1.f : 0.1f;   // operand-ready inputs are already activated
                 p.algo_macs = rows_of(hLs(i), Lc) * (double)(d.up_initial_channel >> i) * (double)(d.up_initial_channel >> (i + 1)) * k;   // Cin*Cout*k*Lin (real widths)
                 if (vl) { p.seg_lin = dLs(i); p.seg_m = dMt(i); p.seg_orows = dLs(i + 1); p.olim_mul = cout; p.seg_m_host = hMt(i); }
-                if ((rc = si_launch_tapgemm(ctx, Ly.ups[i].math, p, st))) return rc;
+                // the early upsamplers (N = 2048 / 1024) on the fp16 stream are real GEMMs: the one-tile-per-CU kernel (gemmcu.hip, TC
+                // mode) wherever it covers the layer's geometry (whatever the batch: the two forms round differently); SI_VOC_UPSGEMM=0: the tap-GEMM
+                int urc = 1;
+                if (r16 && ctx->opt_voc_upsgemm && Ly.ups[i].math == SI_MATH_F16 && Ly.ups[i].has_bias) urc = si_launch_gemmcu_tc(ctx, p, st, true);
+                if (urc < 0) return urc;
+                if (urc > 0 && (rc = si_launch_tapgemm(ctx, Ly.ups[i].math, p, st))) return rc;
             }
             if (!r16 && (rc = si_tap(ctx, upn[i], U, (long)Bc * Lo * cout, st))) return rc;
             // B3: multi-receptive-field fusion: mean over the resblocks, accumulated into xs by the last conv of each
+            const bool act_next = ups_on_gemmcu(i + 1, Lo, cout);   // the launch that completes the sum stores the next upsampler's activated input
             for (int j = 0; j < nk; ++j) {
                 const ResW& R = Ly.rbs[(size_t)i * nk + j];
                 const int rk = d.rb_kernels[j];
@@ -1458,7 +1483,7 @@ static int hifigan_run(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                             q.x = nullptr; q.x16 = y16;
                             if (r16) { q.res = nullptr; q.res16 = y16; q.out = nullptr; }
                             const bool want16 = r16 || !last || (j == nk - 1 && i + 1 < d.num_ups);
-                            if (want16) { q.out16 = ynext16; q.out16_slope = r16 ? 1.f : 0.1f; }
+                            if (want16) { q.out16 = ynext16; q.out16_slope = (r16 && !(act_next && last && j == nk - 1)) ? 1.f : 0.1f; }
                         }
                         q.pro_slope = (opr && !r16) ? 1.f : 0.1f;          // operand-ready inputs are already activated
                         q.nseg = Bc; q.Lin = (int)Lo; q.M = (int)Lo; q.ldx = cout; q.x_seg_stride = Lo * cout;
@@ -1472,7 +1497,7 @@ static int hifigan_run(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                     }
                     continue;
                 }
-                if (r16 && (fuse_mask & cout) && ctx->opt_voc_chain && d.num_dil == 3) {
+                if (r16 && (fuse_mask & cout) && ctx->opt_voc_chain && d.num_dil == 3 && !(act_next && j == nk - 1)) {
                     // full-rate stage: the whole resblock (three pairs) as one kernel, residual stream in LDS (reschain.hip)
                     ResChainParams cp{};
                     cp.y16 = U16; cp.out16 = xs16; cp.B = Bc; cp.L = (int)Lo; cp.k = rk; cp.alpha = 1.0f / nk; cp.accumulate = j > 0;
@@ -1494,7 +1519,8 @@ static int hifigan_run(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                         const TapGemmParams w1 = gemm_params(ctx, R.c1[n]), w2 = gemm_params(ctx, R.c2[n]);
                         unsigned short* yn16 = last_n ? xs16 : h16[4 + (n & 1)];
                         const int frc = si_launch_respair(ctx, cout, y16, yn16, w1.w, w2.w, w1.bias, w2.bias, Bc, (int)Lo, rk, dl,
-                                                          last_n ? 1.0f / nk : 1.0f, last_n && j > 0, st, dLs(i + 1), hLs(i + 1));
+                                                          last_n ? 1.0f / nk : 1.0f, last_n && j > 0, st, dLs(i + 1), hLs(i + 1),
+                                                          (act_next && last_n && j == nk - 1) ? 0.1f : 1.f);
                         if (frc < 0) return frc;
                         if (frc == 0) { y16 = yn16; continue; }
                     }
@@ -1519,7 +1545,7 @@ static int hifigan_run(si_ctx* ctx, const float* mel, int B, int Tm, int stretch
                         // the 16-bit copy is wanted by the next c1 of this block, or -- once the MRF mean is complete --
                         // by the next stage's upsampler; conv_post reads fp32
                         const bool want16 = r16 || !last || (j == nk - 1 && i + 1 < d.num_ups);
-                        if (want16) { q.out16 = ynext16; q.out16_slope = r16 ? 1.f : 0.1f; }
+                        if (want16) { q.out16 = ynext16; q.out16_slope = (r16 && !(act_next && last && j == nk - 1)) ? 1.f : 0.1f; }
                     }
                     q.nseg = Bc; q.Lin = (int)Lo; q.M = (int)Lo; q.ldx = cout; q.x_seg_stride = Lo * cout;
                     q.dil = 1; q.pad = (rk - 1) / 2; q.ldo = cout; q.o_seg_stride = Lo * cout; q.olimit = q.o_seg_stride;

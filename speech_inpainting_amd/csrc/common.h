@@ -146,6 +146,11 @@ struct LinGemmParams {
     // ragged batches: segment s holds seg_m[s] output rows (device int32 (nseg); NULL: M for all); seg_m_host = the same on the host
     const int32_t* seg_m;
     const int32_t* seg_m_host;
+    // gemmcu.hip's transposed-convolution mode (si_launch_gemmcu_tc; fp16 operands and output): tap t of row m reads input row
+    // m + t * tc_dil of a segment of tc_rows_in rows (zeros outside), leaky-ReLU(tc_slope) on the input, output element (m, n) at
+    // m * ldo + n + tc_ooff of its segment, dropped outside [0, tc_olimit)
+    int tc_dil, tc_rows_in; float tc_slope; long tc_ooff, tc_olimit;
+    const int32_t* tc_seg_lin; const int32_t* tc_seg_orows; int tc_olim_mul;   // ragged batches: segment s reads tc_seg_lin[s] rows, keeps [0, tc_seg_orows[s] * tc_olim_mul)
 };
 int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st);
 // The same contract on 256 x 256 tiles with LDS-DMA staging (gemm256.hip), for the shapes whose tiles fill the chip; returns 1 otherwise.
@@ -155,6 +160,10 @@ int si_opt_gemm256(const si_ctx* ctx);      // SI_ENC_GEMM256: 0 never, 1 by the
 // The same contract as ONE tile per CU (gemmcu.hip: 16 waves, tile shape per instantiation), for the flat M = B * T GEMMs of the
 // transformer whose tiles then number at most the CUs; returns 1 otherwise.  Bit-identical to the other two.
 int si_launch_gemmcu(si_ctx* ctx, const LinGemmParams& p, hipStream_t st);
+// The generator's early upsamplers on the fp16 stream as the same kernel (TapGemmParams of a ConvTranspose1d in its two-tap form);
+// SI_OK when launched, negative on error, 1 when the shape is not covered (the caller uses the tap-GEMM).
+int si_launch_gemmcu_tc(si_ctx* ctx, const TapGemmParams& p, hipStream_t st, bool always = false);   // always: also where tiles are mostly padding
+bool si_gemmcu_tc_covers(si_ctx* ctx, const TapGemmParams& p, bool always = false);                   // would the call above launch?
 int si_opt_gemmcu(const si_ctx* ctx);       // SI_ENC_GEMMCU: 0 never, 1 by the shape rule (default), 2 whenever the shape allows, 10 + c: instantiation c
 
 // ------------------------------------------------------------------------------------------------
@@ -332,6 +341,8 @@ struct ResPairParams {
     // ragged batches (NULL: every clip holds L rows): clip b holds lens[b] rows at stride L; lens_host = the same on the host
     const int32_t* lens; const int32_t* lens_host;
     int total_tiles;             // set by the launcher
+    float out_slope;             // 0 or 1: none; otherwise out = leaky_relu(out, out_slope) before the fp16 rounding -- the activation of the
+                                 // only consumer (the next stage's upsampler on gemmcu.hip), applied by the producer (respair_wide.hip only)
 };
 int si_launch_respair_wide(si_ctx* ctx, int C, const ResPairParams& p, hipStream_t st);
 // A whole ResBlock1 -- three (c1, c2) pairs chained, the residual stream kept in LDS -- as one kernel (reschain.hip: C = 32).
@@ -353,7 +364,7 @@ struct ResChainParams {
 int si_launch_reschain(si_ctx* ctx, int C, const ResChainParams& p, hipStream_t st);
 int si_launch_respair(si_ctx* ctx, int C, const unsigned short* y16, unsigned short* out16, const void* w1, const void* w2,
                       const float* b1, const float* b2, int B, int L, int k, int dil, float alpha, int accumulate, hipStream_t st,
-                      const int32_t* lens = nullptr, const int32_t* lens_host = nullptr);
+                      const int32_t* lens = nullptr, const int32_t* lens_host = nullptr, float out_slope = 1.f);
 
 // ------------------------------------------------------------------------------------------------
 // vocoder kernels (vocoder_kernels.hip)

@@ -35,6 +35,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C_BK = 64, C_ROWB = C_BK * 2;                // 128-byte LDS rows
 
@@ -76,7 +78,13 @@ extern "C" int si_debug_gcu_timeline(unsigned long long* out, int reset) {
 #define C_TL_FLUSH
 #endif
 
-template <int NW, int WM, int WN, int MT, int NT, int NS>
+// TC ("transposed convolution" mode, the generator's early upsamplers on the fp16 stream -- I_ea/hifi_gan/models.py:87-95,110-111:
+// x = lrelu(x, 0.1); x = ups[i](x)): fp16 MFMA and fp16 output (one saturating rounding: MODE.FP16_OVFL); tap t of GEMM row m reads
+// input row m + t * tc_dil of the SEGMENT (p.tc_dil = -1: ConvTranspose1d with k = 2 stride as two taps, api.hip) through a
+// descriptor over the segment's own rows, whose range check returns the zeros of the convolution's padding (row -1, row Lin); the
+// leaky-ReLU of the input is applied to the A fragments (max(x, slope x) on packed halves: tapgemm.hip's select for 0 < slope < 1);
+// the output row is shifted by p.tc_ooff elements and cropped to [0, p.tc_olimit) of its segment.
+template <int NW, int WM, int WN, int MT, int NT, int NS, bool TC = false>
 __global__ __launch_bounds__(NW * 64) void gemmcu_kernel(const LinGemmParams p) {
     static_assert(WM * WN == NW, "waves");
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
@@ -108,12 +116,18 @@ __global__ __launch_bounds__(NW * 64) void gemmcu_kernel(const LinGemmParams p) 
     }
     const int n0 = (tile - mtx * ntn) * BN;
 
-    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.x16), 0, p.x_bytes, 0x00020000);
+    if constexpr (TC) __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1);   // MODE.FP16_OVFL: conversions to fp16 saturate at +-65504
+    const int tc_rows = (TC && p.tc_seg_lin) ? p.tc_seg_lin[seg] : p.tc_rows_in;          // (ragged batches: the clip's own rows; scalar loads)
+    const long tc_olimit = (TC && p.tc_seg_orows) ? (long)p.tc_seg_orows[seg] * p.tc_olim_mul : p.tc_olimit;
+    const __amdgpu_buffer_rsrc_t arsrc = TC ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.x16) + (long)seg * p.x_seg_stride, 0, tc_rows * p.lda * 2, 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.x16), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0, p.w_bytes, 0x00020000);
     // LDS-DMA: a piece = 8 rows; lane l lands at physical chunk l & 7 of row l >> 3 and fetches the logical chunk the swizzle puts there
     const int srow = lane >> 3;
     const int lchunk = (lane & 7) ^ (((srow >> 1) & 3) << 1);
-    const int a_lane = (int)(((long)seg * p.x_seg_stride + (long)(m0 + srow) * p.lda) * 2) + lchunk * 16;
+    // (TC: the segment offset is in the descriptor and EVERY row term in the vector offset -- the range check that supplies the zero
+    //  rows looks at the vector offset; a negative one is a huge unsigned one)
+    const int a_lane = TC ? (m0 + srow) * p.lda * 2 + lchunk * 16 : (int)(((long)seg * p.x_seg_stride + (long)(m0 + srow) * p.lda) * 2) + lchunk * 16;
     const int w_lane = (int)(((long)(n0 + srow) * p.Cin) * 2) + lchunk * 16;
     const int cpt = p.Cin / C_BK;
     const int nk = p.K / C_BK;
@@ -127,8 +141,14 @@ __global__ __launch_bounds__(NW * 64) void gemmcu_kernel(const LinGemmParams p) 
             const int piece = wave + NW * q;
             if (piece >= PT) break;
             if (piece < PA) {
-                const int soff = __builtin_amdgcn_readfirstlane(kt * C_BK * 2 + piece * 8 * p.lda * 2);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, C_LDS(buf + piece * 1024), 16, a_lane, soff, 0, 0);
+                if constexpr (TC) {
+                    const int rowterm = __builtin_amdgcn_readfirstlane((piece * 8 + tap * p.tc_dil) * p.lda * 2);
+                    const int soff = __builtin_amdgcn_readfirstlane((kt - tap * cpt) * C_BK * 2);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, C_LDS(buf + piece * 1024), 16, a_lane + rowterm, soff, 0, 0);
+                } else {
+                    const int soff = __builtin_amdgcn_readfirstlane(kt * C_BK * 2 + piece * 8 * p.lda * 2);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, C_LDS(buf + piece * 1024), 16, a_lane, soff, 0, 0);
+                }
             } else {
                 const int soff = __builtin_amdgcn_readfirstlane((int)(koff + (long)(piece - PA) * 8 * p.Cin * 2));
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, C_LDS(buf + piece * 1024), 16, w_lane, soff, 0, 0);
@@ -169,19 +189,34 @@ __global__ __launch_bounds__(NW * 64) void gemmcu_kernel(const LinGemmParams p) 
             // them -- every read but the K-tile's first NT + 1 is issued under MFMAs of the same wave.  Each accumulator still sums
             // k-step 0 before k-step 1: the values do not change.
             bf16x8 fw[NT], fa[2];
+            const _Float16 slope = (_Float16)p.tc_slope;
+            const bool has_act = TC && p.tc_slope != 1.f;              // (uniform: an input its producer already activated skips the VALU work)
+            auto act = [&](bf16x8 v) {                                 // TC: leaky-ReLU on the packed halves of an A fragment
+                if constexpr (TC) {
+                    if (!has_act) return v;
+                    const f16x8 h = __builtin_bit_cast(f16x8, v);
+                    return __builtin_bit_cast(bf16x8, __builtin_elementwise_max(h, h * slope));
+                } else {
+                    return v;
+                }
+            };
+            auto mma = [&](bf16x8 w, bf16x8 a, f32x4 c) {
+                if constexpr (TC) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+                else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0);
+            };
 #pragma unroll
             for (int j = 0; j < NT; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(buf + (w_off + j * 16 * C_ROWB));
-            fa[0] = *reinterpret_cast<const bf16x8*>(buf + a_off);
+            fa[0] = act(*reinterpret_cast<const bf16x8*>(buf + a_off));
 #pragma unroll
             for (int s2 = 0; s2 < 2 * MT; ++s2) {
                 const int ks = s2 / MT, i = s2 - ks * MT;
                 if (s2 + 1 < 2 * MT) {
                     const int ks1 = (s2 + 1) / MT, i1 = (s2 + 1) - ks1 * MT;
-                    fa[(s2 + 1) & 1] = *reinterpret_cast<const bf16x8*>(buf + ((a_off ^ (ks1 * 64)) + i1 * 16 * C_ROWB));
+                    fa[(s2 + 1) & 1] = act(*reinterpret_cast<const bf16x8*>(buf + ((a_off ^ (ks1 * 64)) + i1 * 16 * C_ROWB)));
                 }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[s2 & 1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mma(fw[j], fa[s2 & 1], acc[i][j]);
                     if (s2 == MT - 1) fw[j] = *reinterpret_cast<const bf16x8*>(buf + ((w_off ^ 64) + j * 16 * C_ROWB));
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -228,15 +263,28 @@ __global__ __launch_bounds__(NW * 64) void gemmcu_kernel(const LinGemmParams p) 
                 // lanes l and l + 16 trade halves of a column-tile pair (v_permlane16_swap): 16 bytes per lane, 64 contiguous per row
 #pragma unroll
                 for (int t = 0; t < NT / 2; ++t) {
-                    u32x2 p0 = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[i][2 * t], bf16x4));
-                    u32x2 p1 = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[i][2 * t + 1], bf16x4));
+                    u32x2 p0, p1;
+                    if constexpr (TC) {
+                        p0 = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[i][2 * t], f16x4));
+                        p1 = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[i][2 * t + 1], f16x4));
+                    } else {
+                        p0 = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[i][2 * t], bf16x4));
+                        p1 = __builtin_bit_cast(u32x2, __builtin_convertvector(acc[i][2 * t + 1], bf16x4));
+                    }
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const auto r = __builtin_amdgcn_permlane16_swap(p0[q], p1[q], false, false);
                         p0[q] = r[0]; p1[q] = r[1];
                     }
                     const int col = 16 * (2 * t + (kg & 1)) + 4 * (kg & ~1);
-                    if (live) *reinterpret_cast<u32x4*>(p.out16 + orow + col) = u32x4{p0[0], p0[1], p1[0], p1[1]};
+                    if constexpr (TC) {
+                        // the shifted, cropped output row: element (m, n) lives at m * ldo + n + tc_ooff of its segment; a chunk of 8 is
+                        // wholly inside or outside [0, tc_olimit) (ooff, olimit and the channel count are multiples of 8)
+                        const long flat = (long)m * p.ldo + ncol0 + col + p.tc_ooff;
+                        if (live && flat >= 0 && flat + 8 <= tc_olimit) *reinterpret_cast<u32x4*>(p.out16 + obase + flat) = u32x4{p0[0], p0[1], p1[0], p1[1]};
+                    } else {
+                        if (live) *reinterpret_cast<u32x4*>(p.out16 + orow + col) = u32x4{p0[0], p0[1], p1[0], p1[1]};
+                    }
                 }
             } else {
 #pragma unroll
@@ -256,11 +304,11 @@ struct CuCfg { int bm, bn, ns; };
 static const CuCfg k_cfgs[] = {{320, 256, 2}, {256, 256, 2}, {160, 128, 4}, {224, 128, 3}, {128, 128, 4}, {208, 256, 2}};
 constexpr int k_ncfg = 6, k_nrule = 6;
 
-template <int NW, int WM, int WN, int MT, int NT, int NS>
-static int gemmcu_launch(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
+template <int NW, int WM, int WN, int MT, int NT, int NS, bool TC = false>
+static int gemmcu_launch(si_ctx* ctx, const LinGemmParams& p, hipStream_t st, double algo_macs = 0.0) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     const size_t lds = (size_t)NS * (BM + BN) * C_ROWB;
-    auto kern = gemmcu_kernel<NW, WM, WN, MT, NT, NS>;
+    auto kern = gemmcu_kernel<NW, WM, WN, MT, NT, NS, TC>;
     if (int rc = si_ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kern), lds)) return rc;
     LinGemmParams q = p;
     const int mtiles = (p.M + BM - 1) / BM;
@@ -270,11 +318,11 @@ static int gemmcu_launch(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     const unsigned grid = (unsigned)((tiles + 7) / 8 * 8);
     double rows_real = (double)p.nseg * p.M;
     if (p.seg_m_host) { rows_real = 0; for (int sg = 0; sg < p.nseg; ++sg) rows_real += p.seg_m_host[sg]; }
-    const double macs = rows_real * p.N * (double)p.K;
+    const double macs = algo_macs > 0.0 ? algo_macs : rows_real * p.N * (double)p.K;
     const double outs = rows_real * p.N;
     const double bytes = 2.0 * (rows_real * p.lda + p.nseg * (double)(p.K - p.lda > 0 ? p.K - p.lda : 0)) + outs * ((p.out ? 4 : 0) + (p.out16 ? 2 : 0) + (p.res ? 4 : 0)) + 2.0 * p.N * p.K;
     char name[48];
-    snprintf(name, sizeof(name), "gemmcu_bf16_%dx%d", BM, BN);        // one family per instantiation, as rocprofv3 lists them
+    snprintf(name, sizeof(name), TC ? "gemmcu_f16_%dx%d" : "gemmcu_bf16_%dx%d", BM, BN);        // one family per instantiation, as rocprofv3 lists them
     si_prof_begin(ctx, si_prof_shape_name(name, p.M * (long)p.nseg, p.N, p.K), 2.0 * macs, bytes, st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, q);
     si_prof_end(ctx, st);
@@ -337,4 +385,54 @@ int si_launch_gemmcu(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
         case 4: return gemmcu_launch<8, 2, 4, 4, 2, 4>(ctx, p, st);      // 128 x 128, 8 waves of 64 x 32 (the same at M = 3184)
         default: return gemmcu_launch<8, 1, 8, 13, 2, 2>(ctx, p, st);    // 208 x 256, 8 waves of 208 x 32 (HuBERT-large's FFN1: N = 4096 at M = 6368 / 3184)
     }
+}
+
+// The generator's early upsamplers on the fp16 stream (I_ea/hifi_gan/models.py:87-95,110-111; api.hip hands a ConvTranspose1d with
+// k = 2 stride as a two-tap convolution with dil = -1 and N = stride * Cout): the TC instantiations of the kernel above.
+// the instantiation si_launch_gemmcu_tc would use for this layer (0: 256 x 256, 1: 192 x 256), or -1 when it leaves it to the tap-GEMM
+static int gemmcu_tc_pick(si_ctx* ctx, const TapGemmParams& p, bool always) {
+    if (si_opt_gemmcu(ctx) == 0) return -1;
+    if (!p.x16 || p.x || p.out || !p.out16 || p.out16_slope != 1.f || p.dil != -1 || p.ntaps != 2 || p.stride != 1 || p.pad != 0 || p.groups != 1) return -1;
+    if (p.res || p.res16 || p.accumulate || p.acc16 || p.alpha != 1.f || p.act != SI_ACT_NONE || p.Npad != p.N || p.ldx != p.Cin) return -1;
+    const bool vl = p.seg_lin || p.seg_m || p.seg_orows || p.seg_row_off;
+    if (vl && (!p.seg_lin || !p.seg_m || !p.seg_orows || !p.seg_m_host || p.seg_row_off || p.olim_mul % 8)) return -1;   // ragged batches: per-clip rows in / rows / rows out
+    if (p.Cin % C_BK || p.N % 256 || p.ldo % 8 || p.ooff % 8 || p.olimit % 8 || p.o_seg_stride % 8 || !(p.pro_slope > 0.f && p.pro_slope <= 1.f)) return -1;
+    if (p.M <= 0 || p.nseg <= 0 || (long)(p.Lin + 1) * p.ldx * 2 >= (1L << 30) || (long)(p.M + 320) * p.ldx * 2 >= (1L << 30)) return -1;
+    if ((long)(p.N + 256) * p.Cin * 2 + (long)p.ntaps * p.Npad * p.Cin * 2 >= (1L << 31)) return -1;
+    // tile height by the kernel's cost rule over 256 / 192 rows (BN = 256): rounds x (BM + BN), rows at least 3/4 real (the 320-row
+    // instantiation spills inside its K loop with the activation on the fragments: not built)
+    const int cus = si_num_cus(ctx);
+    int pick = -1;
+    double best = 1e30;
+    const int bms[2] = {256, 192};
+    for (int c = 0; c < 2; ++c) {
+        const long rb = vl ? si_vl_tiles(p.seg_m_host, p.nseg, bms[c]) : (long)p.nseg * ((p.M + bms[c] - 1) / bms[c]);
+        if (rb <= 0) continue;
+        const long tiles = rb * (p.N / 256);
+        const long rounds = (tiles + cus - 1) / cus;
+        double rows_real = (double)p.nseg * p.M;
+        if (vl) { rows_real = 0; for (int sg = 0; sg < p.nseg; ++sg) rows_real += p.seg_m_host[sg]; }
+        if (!always && rows_real < 0.75 * (double)rb * bms[c]) continue;                 // (always: the tests' one-frame clips)
+        const double cost = (double)rounds * (bms[c] + 256);
+        if (cost < best) { best = cost; pick = c; }
+    }
+    return pick;
+}
+
+bool si_gemmcu_tc_covers(si_ctx* ctx, const TapGemmParams& p, bool always) { return gemmcu_tc_pick(ctx, p, always) >= 0; }
+
+int si_launch_gemmcu_tc(si_ctx* ctx, const TapGemmParams& p, hipStream_t st, bool always) {
+    const int pick = gemmcu_tc_pick(ctx, p, always);
+    if (pick < 0) return 1;
+    LinGemmParams q{};
+    q.x16 = p.x16; q.x_bytes = 0; q.lda = p.ldx; q.x_seg_stride = p.x_seg_stride;
+    q.nseg = p.nseg; q.M = p.M; q.K = p.ntaps * p.Cin;
+    q.w = static_cast<const unsigned short*>(p.w); q.w_bytes = p.ntaps * p.Npad * p.Cin * 2;
+    q.N = p.N; q.Cin = p.Cin; q.ntaps = p.ntaps; q.w_tap_stride = (long)p.Npad * p.Cin;
+    q.bias = p.bias; q.out16 = p.out16; q.ldo = p.ldo; q.o_seg_stride = p.o_seg_stride;
+    q.act = SI_ACT_NONE;
+    q.tc_dil = p.dil; q.tc_rows_in = p.Lin; q.tc_slope = p.pro_slope; q.tc_ooff = p.ooff; q.tc_olimit = p.olimit;
+    q.seg_m = p.seg_m; q.seg_m_host = p.seg_m_host; q.tc_seg_lin = p.seg_lin; q.tc_seg_orows = p.seg_orows; q.tc_olim_mul = p.olim_mul;
+    if (pick == 0) return gemmcu_launch<16, 4, 4, 4, 4, 2, true>(ctx, q, st, p.algo_macs);
+    return gemmcu_launch<16, 4, 4, 3, 4, 2, true>(ctx, q, st, p.algo_macs);
 }

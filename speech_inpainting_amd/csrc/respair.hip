@@ -363,12 +363,13 @@ static int respair_launch(si_ctx* ctx, const ResPairParams& p, hipStream_t st) {
 // SI_OK when launched, negative on error, 1 when the shape is not covered (the caller launches the two convolutions).
 int si_launch_respair(si_ctx* ctx, int C, const unsigned short* y16, unsigned short* out16, const void* w1, const void* w2,
                       const float* b1, const float* b2, int B, int L, int k, int dil, float alpha, int accumulate, hipStream_t st,
-                      const int32_t* lens, const int32_t* lens_host) {
+                      const int32_t* lens, const int32_t* lens_host, float out_slope) {
     if ((C != 32 && C != 64 && C != 128 && C != 256) || k < 3 || k > 11 || (k & 1) == 0 || (k - 1) * dil > 50 ||
         ((long)L + 1024) * C * 2 >= (1L << 31)) return 1;
     if (!b1 || !b2) return 1;
     if ((lens == nullptr) != (lens_host == nullptr)) return si_fail(ctx, SI_EINVAL, "respair: ragged batches need the lengths on the device and on the host");
-    ResPairParams p{y16, out16, static_cast<const unsigned short*>(w1), static_cast<const unsigned short*>(w2), b1, b2, B, L, k, dil, alpha, accumulate, lens, lens_host, 0};
+    ResPairParams p{y16, out16, static_cast<const unsigned short*>(w1), static_cast<const unsigned short*>(w2), b1, b2, B, L, k, dil, alpha, accumulate, lens, lens_host, 0, out_slope};
+    if (out_slope != 1.f && C < 128) return 1;                         // (only the wide kernel applies it)
     if (C >= 128) return si_launch_respair_wide(ctx, C, p, st);
     // C = 32: every tap of a convolution in one slab (11 x 2 KB), 256 rows, two 4-wave workgroups per CU
     // C = 64: 4 taps per slab (32 KB), 512 rows, one 8-wave workgroup per CU

@@ -355,6 +355,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
     RPW_TL(4)
     issueW(0);                                                         // slab 0 of the next tile lands during the output pass
     {
+        const bool oact = p.out_slope != 0.f && p.out_slope != 1.f;
 #pragma unroll
         for (int it = 0; it < OPASS; ++it) {
             const int o = or0 + it * ORPP;
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void respair_wide_kernel
                 const float a = e < 4 ? a0[e] : a1[e - 4];
                 float v = (a + (float)rh[e]) * p.alpha;
                 if constexpr (ACC) v += (float)ph[e];
+                if (oact) v = v > 0.f ? v : v * p.out_slope;           // the consumer's leaky-ReLU (uniform branch; see ResPairParams)
                 out[e] = (_Float16)v;                                  // saturating (MODE.FP16_OVFL)
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out), orsrc, goff[it], 0, 0);

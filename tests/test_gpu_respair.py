@@ -79,6 +79,56 @@ def test_streaming_upsamplers_match_the_tap_gemm_form_and_oracle(B, Tm):
     assert bool(torch.isfinite(a).all()) and ((a > 0) == (c > 0)).float().mean().item() > 0.9
 
 
+@pytest.mark.parametrize("B,Tm", [(3, 57), (1, 1), (2, 130), (32, 200), (5, 3)])
+def test_early_upsamplers_on_gemmcu_match_the_tap_gemm_form_and_oracle(B, Tm):
+    """gemmcu.hip's TC instantiations (the 512 -> 256 and 256 -> 128 channel transposed convolutions as two-tap GEMMs with N = 8 Cout:
+    per-clip descriptors whose range check supplies the zero rows, the leaky-ReLU moved into the producers' epilogues, the output row
+    shifted by pad * Cout and cropped) against the tap-GEMM on the same fp16 operands (SI_VOC_UPSGEMM=0) and against the fp32 oracle.  The two forms sum the
+    same products in fp32 in a different order and round to fp16 once; a rounding that flips is amplified by the layers behind it
+    (the bound of the streaming upsamplers' test above).  One-frame clips (the whole clip is padding rows of one tile), clips of
+    several row blocks with a ragged last one, a batch that is several rounds of tiles; every frame at a clip's edge depends on the
+    zero rows; and a stream driven into fp16 overflow must saturate the same way."""
+    from oracle import ref_cpu as R
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import VocoderArch
+    varch = VocoderArch.v1()
+    gsd = synth.synth_generator_state(varch)
+    mel = synth.synth_mel(B, Tm, 80, 83)
+    ref = R.generator_forward(gsd, varch, mel[:4])[:, 0, :]
+
+    def run(flag, m):
+        os.environ["SI_VOC_UPSGEMM"] = flag
+        try:
+            eng = _engine(varch, gsd, True)
+        finally:
+            os.environ.pop("SI_VOC_UPSGEMM", None)
+        eng.ctx.profile_start(4000)
+        w = eng.vocode(m.cuda(), stretch=False).cpu()
+        names = {e["name"] for e in eng.ctx.profile_stop()}
+        assert any(n.startswith("gemmcu_f16_") for n in names) == (flag != "0"), names
+        return w
+
+    new, old = run("1", mel), run("0", mel)
+    assert new.shape == old.shape == (B, Tm * 256) and bool(torch.isfinite(new).all())
+    assert torch.equal(run("1", mel), new)                                            # run to run
+    e_n, e_o, e_no = rms(new[:4], ref), rms(old[:4], ref), rms(new, old)
+    edge = max(rms(new[:, :2048], old[:, :2048]), rms(new[:, -2048:], old[:, -2048:]))
+    print(f"B={B} Tm={Tm}: signal rms {rms(ref):.3f}; gemmcu upsamplers vs oracle {e_n:.3e}, tap-GEMM form vs oracle {e_o:.3e}, one vs the other {e_no:.3e} "
+          f"(clip edges {edge:.3e})")
+    assert e_n <= 2e-4 and e_o <= 2e-4 and e_no <= 2e-4 and edge <= 4e-4
+    assert e_n <= 1.5 * e_o + 1e-5                                                    # no worse than the form it replaces
+    hot = synth.synth_mel(2, 9, 80, 79) * 3.0e4                                       # drives the stream into fp16 overflow
+    a, c = run("1", hot), run("0", hot)
+    assert bool(torch.isfinite(a).all()) and ((a > 0) == (c > 0)).float().mean().item() > 0.9
+    if B > 1:                                                                         # a clip does not depend on its batch neighbours
+        os.environ["SI_VOC_UPSGEMM"] = "1"
+        try:
+            eng = _engine(varch, gsd, True)
+        finally:
+            os.environ.pop("SI_VOC_UPSGEMM", None)
+        assert torch.equal(eng.vocode(mel[1:2].cuda(), stretch=False).cpu(), new[1:2])
+
+
 def test_resblock_chain_kernel_saturates_like_the_pair_kernels():
     """The tap-GEMM form clamps to +-65504 before every fp16 rounding; the fused kernels set MODE.FP16_OVFL instead, so
     that the conversion itself saturates.  A mel scaled until the activation stream overflows fp16 must give a finite

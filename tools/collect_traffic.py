@@ -27,9 +27,9 @@ def family(kernel_name: str) -> str:
         return f"lingemm_bf16_{m.group(1)}x128"
     if "gemm256_kernel" in kernel_name:
         return "gemm256_bf16"
-    m = re.search(r"gemmcu_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", kernel_name)
-    if m:      # bench.py's family name: gemmcu_bf16_<BM>x<BN> (NW, WM, WN, MT, NT, NS: BM = 16 WM MT, BN = 16 WN NT)
-        return f"gemmcu_bf16_{16 * int(m.group(2)) * int(m.group(4))}x{16 * int(m.group(3)) * int(m.group(5))}"
+    m = re.search(r"gemmcu_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (true|false))?>", kernel_name)
+    if m:      # bench.py's family name: gemmcu_{bf16|f16}_<BM>x<BN> (NW, WM, WN, MT, NT, NS, TC: BM = 16 WM MT, BN = 16 WN NT; TC = the fp16 upsamplers)
+        return f"gemmcu_{'f16' if m.group(7) == 'true' else 'bf16'}_{16 * int(m.group(2)) * int(m.group(4))}x{16 * int(m.group(3)) * int(m.group(5))}"
     if "attention_bf16" in kernel_name:
         return "attention_bf16"
     # the fused kernels end in <..., ACC, VL>: ACC = the accumulate variant (bench.py's "_acc"), VL = the ragged-batch instantiation

@@ -327,15 +327,6 @@ static int gemmcu_launch(si_ctx* ctx, const LinGemmParams& p, hipStream_t st, do
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, q);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
-    static const bool twice = getenv("SI_EXP_GEMM_TWICE") != nullptr;  // diagnostic: the same launch again, timed as its own family (operands warm in L2 / MALL)
-    if (twice && p.res != p.out) {
-        char again[64];
-        snprintf(again, sizeof(again), "%s_again", name);
-        si_prof_begin(ctx, si_prof_shape_name(again, p.M * (long)p.nseg, p.N, p.K), 2.0 * macs, bytes, st);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, q);
-        si_prof_end(ctx, st);
-        SI_HIP_CHECK(hipGetLastError());
-    }
     return SI_OK;
 }
 

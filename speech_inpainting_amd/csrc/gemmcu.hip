@@ -8,17 +8,20 @@
 // 2.75 MB per CU in 54 us = 50 GB/s, the rate of the vector-memory path measured in profiles/r03_lingemm_pmc.txt.  The bytes per CU
 // are smallest when a CU's whole share of the output is ONE near-square tile: M * N / 256 outputs per CU is 276 x 276 for FFN1 and
 // 138 x 138 for FFN2 / out-proj.  256 x 256 tiles (gemm256.hip) leave those shapes at 300 (1.17 rounds) and 75 tiles; this kernel
-// takes the tile shape as a template parameter and the launcher picks, per shape, the instantiation whose tiles number at most the
-// CUs and draw the fewest bytes: 320 x 256 (FFN1: 20 x 12 = 240 tiles), 256 x 256 (QKV: 225), 160 x 128 (N = 768: 40 x 6 = 240).
+// takes the tile shape as a template parameter and the launcher picks, per shape, among the instantiations whose tiles fill whole
+// rounds of the CUs, the one that draws the fewest bytes: 320 x 256 (FFN1: 20 x 12 = 240 tiles; conv1 as per-clip segments: 1280 =
+// 5.0 rounds), 256 x 256 (QKV: 225), 160 x 128 (N = 768: 40 x 6 = 240), 208 x 256 / 224 x 128 / 128 x 128 (conv3-6, HuBERT-large).
 //
-// Structure.  NW waves (16 for the 256-column tiles, 8 for 160 x 128) as WM (M) x WN (N); a wave owns (16 MT) x (16 NT) outputs; one
-// workgroup per CU.  Four waves per SIMD (<= 128 registers each) let the hardware interleave one wave's fragment reads with its
-// neighbours' MFMAs -- no hand-made partner schedule as in gemm256.hip, whose 8 waves hold a whole K-tile's fragments.  K-tiles of 64 (whole 128-byte lines of every
-// operand row) arrive by LDS-DMA (buffer_load_dwordx4 ... lds, the XOR swizzle of lingemm.hip applied on the source side) into a
-// ring of NS stages of (BM + BN) x 128 bytes; iteration t = [counted vmcnt: own pieces of K-tile t landed | barrier: everyone's
-// landed, everyone done reading K-tile t - 1 | request K-tile t + NS - 1 into the stage K-tile t - 1 occupied | 2 k-steps of
-// MT x NT MFMAs, one A fragment at a time with the next one's read issued under the current one's MFMAs].  One barrier per K-tile.  Epilogue from the accumulators (bias, fast erf-GELU, residual; bf16 through the half
-// trade of gemm256.hip).
+// Structure.  NW waves (16 for the 320- and 256-row tiles, 8 for the others) as WM (M) x WN (N); a wave owns (16 MT) x (16 NT)
+// outputs; one workgroup per CU.  Four waves per SIMD (<= 128 registers each) let the hardware interleave one wave's fragment reads
+// with its neighbours' MFMAs -- no hand-made partner schedule as in gemm256.hip, whose 8 waves hold a whole K-tile's fragments.
+// K-tiles of 64 (whole 128-byte lines of every operand row) arrive by LDS-DMA (buffer_load_dwordx4 ... lds, the XOR swizzle of
+// lingemm.hip applied on the source side) into a ring of NS stages of (BM + BN) x 128 bytes; iteration t = [counted vmcnt: own
+// pieces of K-tile t landed | barrier: everyone's landed, everyone done reading K-tile t - 1 | request K-tile t + NS - 1 into the
+// stage K-tile t - 1 occupied | 2 k-steps of MT x NT MFMAs, one A fragment at a time with the next one's read issued under the
+// current one's MFMAs].  One barrier per K-tile.  Epilogue from the accumulators (bias, fast erf-GELU, residual; bf16 through the
+// half trade of gemm256.hip).  What bounds it -- the CU's own load path at ~47 GB/s, whatever the tile, wave count or ring depth --
+// and everything that was tried against that: DESIGN.md 4.1e, profiles/r04_gemmcu_ab.txt.
 //
 // BIT-IDENTICAL to lingemm.hip and gemm256.hip: every output's sum runs over K in steps of 32 through the same MFMA with the same
 // operand roles (D^T = W A^T) and the same epilogue arithmetic, so the launcher may choose by shape and batch size without a clip's

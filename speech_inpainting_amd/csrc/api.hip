@@ -82,6 +82,7 @@ struct si_ctx {
     // arithmetic-path options, read from the environment when the context is created (all default to 1)
     bool opt_voc_opready = true, opt_voc_res16 = true, opt_enc_opready = true, opt_att_bf16 = true, opt_enc_lingemm = true;
     bool opt_enc_posconv = true;             // the positional conv on posconv.hip in the bf16 encoder mode (SI_ENC_POSCONV=0: the generic tap-GEMM)
+    int opt_ln_fuse = 1;                     // post-LN layers, bf16 mode: LayerNorm outputs read as residuals are recomputed in the GEMM epilogues (SI_ENC_LNFUSE=0: written)
     int opt_voc_upsgemm = 1;                 // the generator's early upsamplers on gemmcu.hip's TC instantiations (SI_VOC_UPSGEMM=0: the tap-GEMM)
     int opt_ffn_pad = 64;                    // elements of padding behind each row of the bf16 FFN intermediate (SI_ENC_FFNPAD; multiple of 8, <= 128):
                                              // rows 6144 bytes apart are 6272 apart instead -- FFN2 -1.5 % (profiles/r04_ffnpad_ab.txt), same values
@@ -604,7 +605,7 @@ size_t encoder_ws_bytes(const si_model_desc& d, int B, int N) {
     for (int i = 0; i < d.num_conv; ++i) cmax = std::max(cmax, (size_t)e.L[i + 1] * d.conv_dim[i]);
     const size_t BT = (size_t)B * std::max(e.T, 1);
     size_t f = 2 * (size_t)B * cmax + BT * d.conv_dim[d.num_conv - 1] + BT * d.hidden_size * 3 + BT * 3 * d.hidden_size + BT * d.intermediate_size +
-               (size_t)B * d.conv_dim[0] * 2;
+               (size_t)B * d.conv_dim[0] * 2 + BT * 2;                    // (+ the LayerNorm (mean, rstd) rows of the fused post-LN layers)
     // bf16 operand-ready copies (encoder in bf16 mode): LN(features), hidden, attention output, FFN intermediate
     const size_t h16 = (BT * d.conv_dim[d.num_conv - 1] + 2 * BT * d.hidden_size + BT * (d.intermediate_size + 128)) * 2;   // (+ the row padding of the FFN intermediate)
     return f * 4 + h16 + (size_t)B * 16 + (size_t)B * 4 + si_conv0_partials_bytes(B, N) + 41 * 256 +
@@ -645,10 +646,13 @@ TapGemmParams gemm_params(const si_ctx* ctx, const GemmW& G) {
 // y(rows x N) = x(rows x K) W^T + b [+act] [+res]
 // x16 / y16: operand-ready bf16 input (instead of x) / additional-or-only bf16 output, see TapGemmParams
 // ld_in / ld_out (elements; 0 = dense): row strides of the 16-bit input / of the output when they are padded (the FFN intermediate)
+// res_ln (stats, gamma, beta): the residual is LayerNorm(res), recomputed in the GEMM's epilogue (TapGemmParams::res_stats)
+struct ResLn { const float* stats = nullptr; const float* gamma = nullptr; const float* beta = nullptr; };
 int linear(si_ctx* ctx, const GemmW& G, const float* x, float* y, long rows, int act, const float* res, hipStream_t st,
-           const unsigned short* x16 = nullptr, unsigned short* y16 = nullptr, int ld_in = 0, int ld_out = 0) {
+           const unsigned short* x16 = nullptr, unsigned short* y16 = nullptr, int ld_in = 0, int ld_out = 0, ResLn res_ln = ResLn()) {
     TapGemmParams p = gemm_params(ctx, G);
     p.x = x16 ? nullptr : x; p.x16 = x16; p.out = y; p.out16 = y16; p.res = res; p.act = act;
+    p.res_stats = res_ln.stats; p.res_gamma = res_ln.gamma; p.res_beta = res_ln.beta;
     p.nseg = 1; p.Lin = (int)rows; p.M = (int)rows; p.ldx = ld_in ? ld_in : G.Cin; p.x_seg_stride = 0;
     p.ldo = ld_out ? ld_out : G.N; p.o_seg_stride = 0; p.ooff = 0; p.olimit = rows * p.ldo;
     p.lingemm = ctx->opt_enc_lingemm;
@@ -692,6 +696,7 @@ int si_create(si_ctx** out, int device_id, const si_model_desc* desc) {
     ctx->opt_enc_posconv = env_flag("SI_ENC_POSCONV");
     ctx->opt_gemm256 = getenv("SI_ENC_GEMM256") ? atoi(getenv("SI_ENC_GEMM256")) : 1;
     ctx->opt_gemmcu = getenv("SI_ENC_GEMMCU") ? atoi(getenv("SI_ENC_GEMMCU")) : 1;
+    ctx->opt_ln_fuse = getenv("SI_ENC_LNFUSE") ? atoi(getenv("SI_ENC_LNFUSE")) : 1;
     ctx->opt_voc_upsgemm = getenv("SI_VOC_UPSGEMM") ? atoi(getenv("SI_VOC_UPSGEMM")) : 1;
     ctx->opt_ffn_pad = getenv("SI_ENC_FFNPAD") ? std::min(128, std::max(0, atoi(getenv("SI_ENC_FFNPAD")) / 8 * 8)) : 64;
     plan_layout(ctx);
@@ -899,6 +904,15 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     unsigned short* lnf16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * CF * 2)) : nullptr;
     unsigned short* h16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * H * 2)) : nullptr;
     unsigned short* att16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * H * 2)) : nullptr;
+    // Post-LN layers in bf16 mode: a LayerNorm's output is read as a bf16 GEMM operand and as the fp32 residual of the second GEMM
+    // behind it.  The fp32 copy (19.5 MB per launch at the bench shape, 4.7 of the LayerNorm's 14.4 us) is not written: the
+    // LayerNorm stores (mean, rstd) per row and the residual-adding epilogue recomputes the element from the row it was
+    // normalised from -- the SAME expression on the same floats (si_ln_apply), so the values do not change.  The pre-LN sums then
+    // live in ONE buffer that out-proj / FFN2 update in place (each element is read and written by the same lane).
+    // SI_ENC_LNFUSE=0, debug captures, fp32 mode or a width the bf16 GEMM kernels do not cover: every LayerNorm writes its rows.
+    const bool ln_fuse = e16 && ctx->opt_ln_fuse && ctx->opt_enc_lingemm && !d.stable_layer_norm && ctx->dbg_capture.empty() && H % 128 == 0 && I % 64 == 0 &&
+                         (double)(BT + 128) * (I + 128) * 2.0 < 2.0e9;
+    float* ln_stats = ln_fuse ? W.floats(BT * 2) : nullptr;
     const int ffn_ld = e16 ? I + ctx->opt_ffn_pad : I;                 // row stride of the bf16 FFN intermediate (SI_ENC_FFNPAD)
     unsigned short* ffn16 = e16 ? reinterpret_cast<unsigned short*>(W.bytes((size_t)BT * ffn_ld * 2)) : nullptr;
     if (!W.ok) return si_fail(ctx, SI_ENOMEM, "internal: encoder workspace carve exceeded its own estimate");
@@ -1003,8 +1017,10 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
         if ((rc = si_launch_tapgemm(ctx, L.pos.math, p, st))) return rc;
     }
     const float eps = d.layer_norm_eps;
+    ResLn cur_ln;                                                      // ln_fuse: the LayerNorm whose (unwritten) output is the current hidden state
     if (!d.stable_layer_norm) {
-        if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, L.enc_ln_g), wf(ctx, L.enc_ln_b), h, BT, H, eps, 0, st, h16))) return rc;
+        if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, L.enc_ln_g), wf(ctx, L.enc_ln_b), ln_fuse ? nullptr : h, BT, H, eps, 0, st, h16, ln_stats))) return rc;
+        cur_ln = ResLn{ln_stats, wf(ctx, L.enc_ln_g), wf(ctx, L.enc_ln_b)};
     } else {
         std::swap(h, h2);
     }
@@ -1017,19 +1033,33 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
             if (qkv_bf16) rc = si_launch_attention_bf16in(ctx, qkv16, B, T, H, d.num_heads, st, att16, vframes, d_rowoff, sum_t2);
             else rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16, vframes, d_rowoff, sum_t2);
             if (rc) return rc;
+            if (ln_fuse) {
+                // h2 holds the rows the current hidden state was normalised FROM; out-proj / FFN2 add their residual LayerNorm(h2)
+                // from it and write the next pre-LN sum over it.  The last layer's (or the asked-for layer's) output is written.
+                const bool want_rows = l + 1 == d.num_layers || output_layer == l + 1;
+                if ((rc = linear(ctx, Wl.out, att, h2, BT, SI_ACT_NONE, h2, st, att16, nullptr, 0, 0, cur_ln))) return rc;
+                if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), nullptr, BT, H, eps, 0, st, h16, ln_stats))) return rc;
+                cur_ln = ResLn{ln_stats, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b)};
+                if ((rc = linear(ctx, Wl.ffn1, h, nullptr, BT, SI_ACT_GELU, nullptr, st, h16, ffn16, 0, ffn_ld))) return rc;
+                if ((rc = linear(ctx, Wl.ffn2, ffn, h2, BT, SI_ACT_NONE, h2, st, ffn16, nullptr, ffn_ld, 0, cur_ln))) return rc;
+                if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), want_rows ? h : nullptr, BT, H, eps, 0, st, h16, ln_stats))) return rc;
+                cur_ln = ResLn{ln_stats, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b)};
+            } else {
             if ((rc = linear(ctx, Wl.out, att, h2, BT, SI_ACT_NONE, h, st, att16))) return rc;
             if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h, BT, H, eps, 0, st, h16))) return rc;
             if ((rc = linear(ctx, Wl.ffn1, h, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16, 0, e16 ? ffn_ld : 0))) return rc;
             if ((rc = linear(ctx, Wl.ffn2, ffn, h2, BT, SI_ACT_NONE, h, st, ffn16, nullptr, e16 ? ffn_ld : 0))) return rc;
             if ((rc = si_launch_layernorm(ctx, h2, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h, BT, H, eps, 0, st, h16))) return rc;
+            }
         } else {                          // pre-LN "stable" (modeling_hubert.py:504-547); residual adds are in place
-            if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), h2, BT, H, eps, 0, st, h16))) return rc;
+            // (bf16 mode: the normalised rows feed GEMMs only -- their bf16 operand is all that is written)
+            if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln1_g), wf(ctx, Wl.ln1_b), e16 ? nullptr : h2, BT, H, eps, 0, st, h16))) return rc;
             if ((rc = linear(ctx, Wl.qkv, h2, qkv_bf16 ? nullptr : qkv, BT, SI_ACT_NONE, nullptr, st, h16, qkv_bf16 ? qkv16 : nullptr))) return rc;
             if (qkv_bf16) rc = si_launch_attention_bf16in(ctx, qkv16, B, T, H, d.num_heads, st, att16, vframes, d_rowoff, sum_t2);
             else rc = si_launch_attention(ctx, qkv, att, B, T, H, d.num_heads, st, att16, ctx->opt_att_bf16, vframes, d_rowoff, sum_t2);
             if (rc) return rc;
             if ((rc = linear(ctx, Wl.out, att, h, BT, SI_ACT_NONE, h, st, att16))) return rc;
-            if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), h2, BT, H, eps, 0, st, h16))) return rc;
+            if ((rc = si_launch_layernorm(ctx, h, nullptr, wf(ctx, Wl.ln2_g), wf(ctx, Wl.ln2_b), e16 ? nullptr : h2, BT, H, eps, 0, st, h16))) return rc;
             if ((rc = linear(ctx, Wl.ffn1, h2, e16 ? nullptr : ffn, BT, SI_ACT_GELU, nullptr, st, h16, ffn16, 0, e16 ? ffn_ld : 0))) return rc;
             if ((rc = linear(ctx, Wl.ffn2, ffn, h, BT, SI_ACT_NONE, h, st, ffn16, nullptr, e16 ? ffn_ld : 0))) return rc;
         }

@@ -86,6 +86,9 @@ struct TapGemmParams {
     const void* w_lo;      // bf16x3: lo plane, same layout
     const float* bias;     // [groups*N] or nullptr
     const float* res;      // residual, indexed like out, or nullptr
+    // res_stats != NULL: the residual is LayerNorm(res) -- res holds the rows BEFORE the normalisation, res_stats (mean, rstd) per row,
+    // res_gamma / res_beta its affine pair (the normalised rows were written as a bf16 GEMM operand only); bf16 GEMM kernels only
+    const float* res_stats; const float* res_gamma; const float* res_beta;
     const unsigned short* res16;  // residual as raw 16-bit values of the math mode's type (instead of res)
     int acc16;             // accumulate reads the previous value from out16 (raw 16-bit) instead of out
     float* out;            // fp32 output (may be NULL when only out16 is wanted)
@@ -138,6 +141,7 @@ struct LinGemmParams {
     const unsigned short* w; int w_bytes;
     int N, Cin, ntaps; long w_tap_stride;       // elements between tap blocks of W
     const float* bias; const float* res;        // res: fp32, indexed like out
+    const float* res_stats; const float* res_gamma; const float* res_beta;   // see TapGemmParams
     float* out; unsigned short* out16;          // fp32 and / or bf16 output
     int ldo; long o_seg_stride;
     int act;
@@ -200,7 +204,7 @@ size_t si_conv0_partials_bytes(int B, int N);
 // y = LN(x [+ add]) * gamma + beta over the last dim C (rows x C), optional GELU afterwards
 // y16 (optional): bf16 copy of y for a bf16 GEMM consumer; y may then be NULL (bf16 output only)
 int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const float* gamma, const float* beta, float* y,
-                        long rows, int C, float eps, int gelu, hipStream_t st, unsigned short* y16 = nullptr);
+                        long rows, int C, float eps, int gelu, hipStream_t st, unsigned short* y16 = nullptr, float* stats = nullptr);
 
 // softmax(q k^T / sqrt(64)) v for head_dim 64; qkv (B, T, 3H) packed [q | k | v]; out (B, T, H)
 // out16 (optional): write the result as bf16 there INSTEAD of fp32 into out
@@ -298,6 +302,10 @@ __device__ __forceinline__ float si_gelu_fast(float x) {
     const float erf = __builtin_copysignf(fmaf(-poly, e, 1.0f), z);
     return 0.5f * x * (1.0f + erf);
 }
+
+// LayerNorm applied to one element: the ONE expression of it on the path.  layernorm_kernel writes y with it; a GEMM epilogue whose
+// residual is a LayerNorm output that was never stored (LinGemmParams::res_stats) recomputes the same value from the same floats.
+__device__ __forceinline__ float si_ln_apply(float x, float mean, float rstd, float g, float b) { return fmaf((x - mean) * rstd, g, b); }
 
 // leaky-ReLU(0.1) of an accumulator as max(v, 0.1 v) in two VALU ops: fmaxf() would first canonicalise both operands
 // (a v_max_f32 v, v, v each), which nothing downstream of an MFMA accumulator needs

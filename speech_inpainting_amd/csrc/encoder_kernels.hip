@@ -22,6 +22,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -375,7 +376,7 @@ template <bool GELU, int NS>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ y, unsigned short* __restrict__ y16, long rows, int C,
-                                                        float eps) {
+                                                        float eps, float* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
     const long nwaves = (long)gridDim.x * 4;
     long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             }
         }
         const float rstd = rsqrtf(wave_sum(q) / C + eps);
+        if (stats && lane == 0) *reinterpret_cast<f32x2*>(stats + 2 * row) = f32x2{mean, rstd};   // for a consumer that recomputes y (si_ln_apply)
         float* yr = y + row * C;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = (v[j][e] - mean) * rstd * g[e] + bt[e];
+                    float t = si_ln_apply(v[j][e], mean, rstd, g[e], bt[e]);
                     o[e] = GELU ? (y ? gelu_erf(t) : si_gelu_fast(t)) : t;   // bf16-only output: the GEMM epilogues' erf (common.h)
                 }
                 if (y) *reinterpret_cast<f32x4*>(yr + i) = o;           // (y16 alone: the only consumer is a bf16 GEMM)
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const float* gamma, const float* beta, float* y,
-                        long rows, int C, float eps, int gelu, hipStream_t st, unsigned short* y16) {
+                        long rows, int C, float eps, int gelu, hipStream_t st, unsigned short* y16, float* stats) {
     if (C % 4 != 0 || C > 2048) return si_fail(ctx, SI_EINVAL, "layernorm width %d must be a multiple of 4 and <= 2048", C);
     if (rows <= 0) return SI_OK;
     // 16 waves per CU (four 4-wave workgroups), each walking its share of the rows (same-box A/B over 8 / 16 / 32 waves
@@ -447,10 +449,10 @@ int si_launch_layernorm(si_ctx* ctx, const float* x, const float* add, const flo
     dim3 grid((unsigned)std::min<long>((rows + 3) / 4, (long)si_num_cus(ctx) * per_cu));
     if (!y && !y16) return si_fail(ctx, SI_EINVAL, "layernorm: no output");
     si_prof_begin(ctx, "layernorm", 8.0 * rows * C, (4.0 + (add ? 4.0 : 0.0) + (y ? 4.0 : 0.0) + (y16 ? 2.0 : 0.0)) * rows * C, st);
-    if (gelu && narrow) hipLaunchKernelGGL((layernorm_kernel<true, 4>), grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
-    else if (gelu) hipLaunchKernelGGL((layernorm_kernel<true, 8>), grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
-    else if (narrow) hipLaunchKernelGGL((layernorm_kernel<false, 4>), grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
-    else hipLaunchKernelGGL((layernorm_kernel<false, 8>), grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps);
+    if (gelu && narrow) hipLaunchKernelGGL((layernorm_kernel<true, 4>), grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps, stats);
+    else if (gelu) hipLaunchKernelGGL((layernorm_kernel<true, 8>), grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps, stats);
+    else if (narrow) hipLaunchKernelGGL((layernorm_kernel<false, 4>), grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps, stats);
+    else hipLaunchKernelGGL((layernorm_kernel<false, 8>), grid, dim3(256), 0, st, x, add, gamma, beta, y, y16, rows, C, eps, stats);
     si_prof_end(ctx, st);
     SI_HIP_CHECK(hipGetLastError());
     return SI_OK;

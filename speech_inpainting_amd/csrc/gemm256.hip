@@ -42,6 +42,7 @@
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(G_NT, 2) void gemm256_kernel(const LinGemmParams p)
 
     const bool gelu = p.act == SI_ACT_GELU;
     const bool has_res = p.res != nullptr;
+    const bool res_ln = p.res_stats != nullptr;
     G_TL(0)
     for (int it = 0;; ++it) {
         const TileRef nxt = decode(it + 1);
@@ -269,6 +271,16 @@ __global__ __launch_bounds__(G_NT, 2) void gemm256_kernel(const LinGemmParams p)
             if (has_res) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) rv[j] = *reinterpret_cast<const f32x4*>(p.res + orow + 16 * j + 4 * kg);
+                if (res_ln) {                                          // the residual is LayerNorm(res): si_ln_apply on the row's (mean, rstd)
+                    const f32x2 ms = *reinterpret_cast<const f32x2*>(p.res_stats + 2 * (long)(live ? m : cur.M - 1));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 lg = *reinterpret_cast<const f32x4*>(p.res_gamma + ncol0 + 16 * j + 4 * kg);
+                        const f32x4 lb = *reinterpret_cast<const f32x4*>(p.res_beta + ncol0 + 16 * j + 4 * kg);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rv[j][e] = si_ln_apply(rv[j][e], ms[0], ms[1], lg[e], lb[e]);
+                    }
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -317,6 +329,7 @@ int si_launch_gemm256(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     double rows_real = (double)p.nseg * p.M;
     if (p.seg_m_host) { rows_real = 0; for (int s = 0; s < p.nseg; ++s) rows_real += p.seg_m_host[s]; }
     if (p.seg_m && !p.seg_m_host) return 1;
+    if (p.res_stats && p.nseg != 1) return 1;                          // a LayerNorm residual: one flat segment
     // The results are bit-identical to lingemm's (same K order, same MFMA and operand roles, same epilogue), so the choice is
     // purely one of speed and may depend on the batch: 256-row tiles with one workgroup per CU pay when the tiles fill whole
     // rounds of the chip's CUs and few of their rows are padding.  (B = 32 x 4 s, HuBERT-base: the first four strided

@@ -34,6 +34,7 @@
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(NW * 64) void gemmcu_kernel(const LinGemmParams p) 
     // ---- epilogue from the accumulators: lane (r16, kg) holds row 16 i + r16, columns 16 j + 4 kg + [0, 4) of the wave's tile
     const bool gelu = p.act == SI_ACT_GELU;
     const bool has_res = p.res != nullptr;
+    const bool res_ln = p.res_stats != nullptr;
     const long obase = (long)seg * p.o_seg_stride;
     const int ncol0 = n0 + wc * NT * 16;
     f32x4 bv[NT];
@@ -249,6 +251,16 @@ __global__ __launch_bounds__(NW * 64) void gemmcu_kernel(const LinGemmParams p) 
         if (has_res) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) rv[j] = *reinterpret_cast<const f32x4*>(p.res + orow + 16 * j + 4 * kg);
+            if (res_ln) {                                              // the residual is LayerNorm(res): si_ln_apply on the row's (mean, rstd)
+                const f32x2 ms = *reinterpret_cast<const f32x2*>(p.res_stats + 2 * (long)(live ? m : Ms - 1));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const f32x4 lg = *reinterpret_cast<const f32x4*>(p.res_gamma + ncol0 + 16 * j + 4 * kg);
+                    const f32x4 lb = *reinterpret_cast<const f32x4*>(p.res_beta + ncol0 + 16 * j + 4 * kg);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv[j][e] = si_ln_apply(rv[j][e], ms[0], ms[1], lg[e], lb[e]);
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -340,6 +352,7 @@ int si_launch_gemmcu(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     const int opt = si_opt_gemmcu(ctx);
     if (opt == 0) return 1;
     if (p.seg_m && !p.seg_m_host) return 1;                            // ragged segments need their host copy for the grid
+    if (p.res_stats && p.nseg != 1) return 1;                          // a LayerNorm residual: one flat segment (the row index is the stats index)
     if (p.Cin % C_BK || p.K % C_BK || p.K != p.ntaps * p.Cin || p.ldo % 4 || p.lda % 8 || p.M <= 0 || p.nseg <= 0 || p.N % 128) return 1;
     if (p.x_bytes <= 0 || p.w_bytes <= 0 || (long)p.nseg * p.x_seg_stride * 2 + (long)(p.M + 320) * p.lda * 2 >= (1L << 31)) return 1;
     if ((long)(p.N + 256) * p.Cin * 2 + (long)p.ntaps * p.w_tap_stride * 2 >= (1L << 31)) return 1;

@@ -50,6 +50,7 @@
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -81,6 +82,10 @@ __device__ __forceinline__ void lg_epilogue(const LinGemmParams& p, char* smem, 
     const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     const long obase = (long)seg * p.o_seg_stride;
     const bool gelu = p.act == SI_ACT_GELU;
+    // res_stats: the residual is LayerNorm(res), recomputed from the rows before the normalisation (common.h: si_ln_apply)
+    const bool res_ln = p.res_stats != nullptr;
+    f32x4 lg = {0.f, 0.f, 0.f, 0.f}, lb = {0.f, 0.f, 0.f, 0.f};
+    if (res_ln) { lg = *reinterpret_cast<const f32x4*>(p.res_gamma + n); lb = *reinterpret_cast<const f32x4*>(p.res_beta + n); }
 #pragma unroll 4
     for (int it = 0; it < BM / 8; ++it) {
         const int r = er0 + 8 * it;
@@ -94,7 +99,15 @@ __device__ __forceinline__ void lg_epilogue(const LinGemmParams& p, char* smem, 
             if (gelu) x = si_gelu_fast(x);
             v[e] = x;
         }
-        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
+        if (p.res) {
+            f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + o);
+            if (res_ln) {
+                const f32x2 ms = *reinterpret_cast<const f32x2*>(p.res_stats + 2 * (long)m);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rr[e] = si_ln_apply(rr[e], ms[0], ms[1], lg[e], lb[e]);
+            }
+            v += rr;
+        }
         if (p.out) *reinterpret_cast<f32x4*>(p.out + o) = v;
         if (p.out16) *reinterpret_cast<bf16x4*>(p.out16 + o) = __builtin_convertvector(v, bf16x4);
     }
@@ -272,6 +285,7 @@ int si_launch_lingemm(si_ctx* ctx, const LinGemmParams& p, hipStream_t st) {
     if (p.N % LG_BN || p.Cin % LG_BK || p.K % LG_BK || p.K != p.ntaps * p.Cin || p.ldo % 4 || p.lda % 8 || p.M <= 0 || p.nseg <= 0) return 1;
     if (p.x_bytes <= 0 || p.w_bytes <= 0 || (long)p.nseg * p.x_seg_stride * 2 + (long)(p.M + 128) * p.lda * 2 >= (1L << 31)) return 1;
     if (!p.out && !p.out16) return si_fail(ctx, SI_EINVAL, "lingemm: no output");
+    if (p.res_stats && (!p.res || !p.res_gamma || !p.res_beta || p.nseg != 1)) return si_fail(ctx, SI_EINVAL, "lingemm: a LayerNorm residual needs res, gamma, beta and one flat segment");
     {
         int rc = si_launch_gemmcu(ctx, p, st);                         // one tile per CU where that is one round of the chip (bit-identical results)
         if (rc <= 0) return rc;

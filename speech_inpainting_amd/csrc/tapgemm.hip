@@ -769,12 +769,13 @@ int si_launch_tapgemm(si_ctx* ctx, int math, const TapGemmParams& p, hipStream_t
         q.nseg = p.nseg; q.M = p.M; q.K = p.ntaps * p.Cin;
         q.w = static_cast<const unsigned short*>(p.w); q.w_bytes = p.ntaps * p.Npad * p.Cin * 2;
         q.N = p.N; q.Cin = p.Cin; q.ntaps = p.ntaps; q.w_tap_stride = (long)p.Npad * p.Cin;
-        q.bias = p.bias; q.res = p.res; q.out = p.out; q.out16 = p.out16; q.ldo = p.ldo; q.o_seg_stride = p.nseg > 1 ? p.o_seg_stride : 0;
+        q.bias = p.bias; q.res = p.res; q.res_stats = p.res_stats; q.res_gamma = p.res_gamma; q.res_beta = p.res_beta; q.out = p.out; q.out16 = p.out16; q.ldo = p.ldo; q.o_seg_stride = p.nseg > 1 ? p.o_seg_stride : 0;
         q.act = p.act;
         q.seg_m = p.seg_m; q.seg_m_host = p.seg_m_host;                 // (ragged: rows >= seg_m[s] of a segment are neither computed nor stored)
         const int rc = si_launch_lingemm(ctx, q, st);
         if (rc <= 0) return rc;
     }
+    if (p.res_stats) return si_fail(ctx, SI_EINVAL, "tapgemm: a LayerNorm residual (res_stats) is taken by the bf16 GEMM kernels only, which do not cover this shape");
     const bool k32 = (p.Cin % 32 == 0);
     switch (math) {
         case SI_MATH_F32: return k32 ? launch_math<SI_MATH_F32, 32>(ctx, p, st) : launch_math<SI_MATH_F32, 16>(ctx, p, st);

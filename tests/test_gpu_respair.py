@@ -319,6 +319,37 @@ def test_gemmcu_matches_lingemm_in_the_bf16_encoder(arch, B, N, flag):
     assert torch.equal(outs[flag], outs["0"])
 
 
+@pytest.mark.parametrize("env", [{"SI_ENC_GEMMCU": "0", "SI_ENC_GEMM256": "0"}, {"SI_ENC_GEMMCU": "0", "SI_ENC_GEMM256": "2"}, {"SI_ENC_GEMMCU": "2"}, {}])
+def test_layernorm_residual_fusion_changes_no_value(env):
+    """Post-LN layers in bf16 mode (SI_ENC_LNFUSE, default 1): a LayerNorm writes its bf16 GEMM operand and (mean, rstd) per row but
+    not its fp32 rows; the epilogue of the GEMM that adds them as its residual (out-proj, FFN2 -- in lingemm.hip, gemm256.hip and
+    gemmcu.hip) recomputes each element from the row it was normalised from with the LayerNorm kernel's own expression
+    (si_ln_apply), and updates the pre-LN sums in place.  The features must be EQUAL to the run in which every LayerNorm writes
+    its rows (SI_ENC_LNFUSE=0), with each of the three GEMM kernels forced, and with the launcher's own choice at B = 32."""
+    from speech_inpainting_amd import synth
+    from speech_inpainting_amd.arch import HubertArch, VocoderArch
+    from speech_inpainting_amd.engine import InpaintingEngine
+    harch, varch = HubertArch.base(), VocoderArch.tiny()
+    hsd, gsd, cb = synth.synth_hubert_state(harch), synth.synth_generator_state(varch), synth.synth_codebook(50)
+    wave = synth.synth_wave(3 if env else 32, 30000 if env else 64000, 99).cuda()
+    outs = {}
+    for fuse in ("1", "0"):
+        os.environ.update(env)
+        os.environ["SI_ENC_LNFUSE"] = fuse
+        try:
+            eng = InpaintingEngine(harch, varch, 50, "cuda:0", "bf16", "fp32").load_state(hsd, gsd, cb)
+        finally:
+            for k in list(env) + ["SI_ENC_LNFUSE"]:
+                os.environ.pop(k, None)
+        outs[fuse] = eng.encode(wave).cpu()
+        if fuse == "1":
+            assert torch.equal(eng.encode(wave).cpu(), outs["1"])                      # (the in-place update: run to run)
+            if env:
+                assert torch.equal(eng.encode(wave[1:2].contiguous()).cpu(), outs["1"][1:2])
+    assert bool(torch.isfinite(outs["1"]).all())
+    assert torch.equal(outs["1"], outs["0"])
+
+
 def test_ffn_row_padding_changes_no_value():
     """SI_ENC_FFNPAD: the bf16 FFN intermediate is stored with padded rows (default 64 elements: FFN2's operand rows then start
     6272 instead of 6144 bytes apart); a layout choice only -- the encoder output equals the dense layout's bit for bit."""

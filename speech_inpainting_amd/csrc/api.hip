@@ -987,7 +987,8 @@ static int hubert_run(si_ctx* ctx, const float* wav, const int32_t* mask_start, 
     // A3: LN + projection
     const float* pin = feat;
     if (d.feat_proj_layer_norm) {
-        if ((rc = si_launch_layernorm(ctx, feat, nullptr, wf(ctx, L.fp_ln_g), wf(ctx, L.fp_ln_b), lnf, BT, CF, d.layer_norm_eps, 0, st, lnf16))) return rc;
+        // (bf16 mode: the projection reads the bf16 operand only)
+        if ((rc = si_launch_layernorm(ctx, feat, nullptr, wf(ctx, L.fp_ln_g), wf(ctx, L.fp_ln_b), lnf16 ? nullptr : lnf, BT, CF, d.layer_norm_eps, 0, st, lnf16))) return rc;
         pin = lnf;
     }
     if ((rc = linear(ctx, L.proj, pin, h, BT, SI_ACT_NONE, nullptr, st, d.feat_proj_layer_norm ? lnf16 : nullptr))) return rc;
